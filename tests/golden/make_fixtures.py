@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (imported from
+/root/reference/src) on small seeded inputs.  Build-container only: the
+reference never travels to the GPU box, only these arrays do.
+
+Usage:  python tests/golden/make_fixtures.py            (writes next to itself)
+
+Import recipe: five third-party modules the reference
+imports are absent from this image (xarray, numba, numba_scipy, geopy,
+regionmask); none of them is on the numeric path, so inert stand-in modules
+are registered before the import.  The parts of the reference that really
+need xarray (Field/MultiField construction, the DataFrame.to_xarray tail of
+Predictor.__call__) are bypassed: MultiField objects are created with
+object.__new__ and given the attributes the numeric code reads, and the
+solve lines of joint Predictor.__call__ (src/joint_prediction.py:67-78) are
+replayed with the same scipy calls on the matrices the reference's own
+_pred_cov/_pred_cross_cov/_joint_cov methods return.
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src"
+
+
+def _import_reference():
+    collections.Iterable = collections.abc.Iterable  # src/data_utils.py:3 on py>=3.10
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def ident(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    class _Placeholder:
+        def __init__(self, *a, **k):
+            pass
+
+    stub("numba", njit=ident, vectorize=ident, guvectorize=ident, float64=float)
+    stub("numba_scipy")
+    stub("xarray", Dataset=_Placeholder, DataArray=_Placeholder, open_dataset=None, apply_ufunc=None)
+    g = stub("geopy")
+    g.distance = stub("geopy.distance", geodesic=None)
+    r = stub("regionmask")
+    r.__path__ = []
+    r.defined_regions = stub("regionmask.defined_regions", natural_earth=None)
+    sys.path.insert(0, REF)
+    import fields
+    import joint_prediction
+    import model
+    import point_prediction
+    import sim
+    return model, fields, sim, joint_prediction, point_prediction
+
+
+model, fields, sim, joint_prediction, point_prediction = _import_reference()
+from scipy.linalg import LinAlgError, cho_factor, cho_solve  # noqa: E402
+
+# ---- parameter sets ---------------------------------
+SET_A = [0.99, 0.81, 0.39, 0.695, 1.0, 460, 460, 460, 0.02, 0.025, -0.19]
+SET_B = [1, 1, 1.5, 1.5, 1.5, 400, 400, 400, 0.02, 0.02, -0.6]
+SET_R = [0.988554, 0.813300, 0.390812, 3.499987, 0.998611, 446.350416, 499.967591, 468.516220,
+         0.0, 0.024783, -0.189985]  # research/modelling_comparison.ipynb:1065-1072
+SET_S = [1.022804, 1.111082, 0.761062, 3.5, 0.865863, 366.394072, 2000.0, 665.881210,
+         0.057784, 0.025702, 0.200037]  # research/modelling_demo_sif.ipynb cell 8 (indefinite)
+SET_KAT = [1.0, 1.0, 1.5, 1.5, 1.5, 0.2, 0.2, 0.2, 0.0, 0.0, -0.6]  # simulation_experiment.ipynb:63
+SET_U = [1.0, 1.0, 0.8, 1.3, 2.2, 0.25, 0.3, 0.2, 0.01, 0.0, 0.45]  # unit-square, generic nu
+
+
+def make_model(vals, n_procs=2):
+    p = model.MaternParams(n_procs=n_procs)
+    p.set_values(np.asarray(vals, dtype=float))
+    return model.MultivariateMatern(n_procs=n_procs, params=p)
+
+
+class _F:
+    pass
+
+
+def make_mf(coords, values, coords_all=None, values_all=None):
+    fl = []
+    for k in range(len(coords)):
+        f = _F()
+        f.coords_main = np.asarray(coords[k], dtype=float)
+        f.values_main = np.asarray(values[k], dtype=float)
+        f.coords = f.coords_main if coords_all is None else np.asarray(coords_all[k], dtype=float)
+        f.values = f.values_main if values_all is None else np.asarray(values_all[k], dtype=float)
+        f.timestamp = np.nan
+        f.size = len(f.values)
+        fl.append(f)
+    mf = object.__new__(fields.MultiField)
+    arr = np.empty(len(fl), dtype=object)
+    for k, f in enumerate(fl):
+        arr[k] = f
+    mf.fields = arr
+    mf.n_procs = len(fl)
+    mf.timestamp = np.nan
+    mf.timedeltas = [np.nan, np.nan]
+    return mf
+
+
+def ref_joint(mod, mf, i, pcoords, metric, cv_ix=None, verify=False):
+    """Reference joint Predictor: its own assembly methods + the solve lines replayed."""
+    kw = dict(fast_dist=True, dist_units="km") if metric == 0 else dict(fast_dist=False, dist_units=None)
+    P = joint_prediction.Predictor(mod, mf, **kw)
+    P.i = i
+    pc = np.atleast_2d(np.asarray(pcoords, dtype=float))
+    c0 = P._pred_cross_cov(pc, cv_ix=cv_ix)
+    S = P._joint_cov(cv_ix=cv_ix)
+    data = [mf.fields[k].values_main.copy() for k in range(mf.n_procs)]
+    warned = False
+    if cv_ix is not None:
+        data[i] = np.delete(data[i], cv_ix, axis=0)
+    elif verify:
+        try:
+            joint_prediction._verify_model(P._pred_cov(pc), c0, S)
+        except LinAlgError:
+            warned = True
+    # src/joint_prediction.py:67-78 replayed on the reference's own matrices
+    stacked = np.hstack(data)
+    W = cho_solve(cho_factor(S.copy(), lower=True, overwrite_a=True, check_finite=False),
+                  c0.copy(), overwrite_b=True, check_finite=False).T
+    var = np.diagonal(P._pred_cov(pc) - np.matmul(W, c0))
+    pred = W @ stacked
+    with np.errstate(invalid="ignore"):
+        pred_err = np.nan_to_num(np.sqrt(var))
+    return dict(pred=pred, pred_err=pred_err, S=S, c0=c0, W=W, warned=warned)
+
+
+def conus_points(rng, n):
+    lat = rng.uniform(25.0, 50.0, n)
+    lon = rng.uniform(-122.0, -70.0, n)
+    return np.column_stack([lat, lon])
+
+
+def lattice_points(rng, n, step=0.05):
+    """distinct 0.05-degree cell centres in the CONUS box (create_residuals.ipynb:417 lattice)."""
+    nlat, nlon = int(round(36 / step)), int(round(60 / step))
+    idx = rng.choice(nlat * nlon, size=n, replace=False)
+    lat = 22.0 + step / 2 + (idx // nlon) * step
+    lon = -125.0 + step / 2 + (idx % nlon) * step
+    return np.column_stack([lat, lon])
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KB")
+
+
+# ===========================================================================
+def fixture_kat():
+    """The reference's one known-answer test: research/simulation_experiment.ipynb
+    cells 3-5, 11 (cokriging of process 1) and cell 14 (kriging of process 1 alone)."""
+    mod = make_model(SET_KAT)
+    grid = sim.CartesianGrid(xcount=51, ycount=51)
+    rf = sim.BivariateRandomField(mod, grid, seed=1)
+    samples = rf.sample(size=100, epsilon=np.sqrt(0.01))
+    # rf.to_fields(): outer merge -> set_index([x,y]).to_xarray() -> to_dataframe().dropna()
+    # leaves each process' samples sorted by (x, y).
+    S = [s.sort_values(["x", "y"]).reset_index(drop=True) for s in samples]
+    coords = [S[k][["x", "y"]].values for k in range(2)]
+    values = [S[k][f"Z{k}"].values for k in range(2)]
+    pcoords = grid.coords.values
+    mf = make_mf(coords, values)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = ref_joint(mod, mf, 1, pcoords, metric=1)
+    # recorded notebook digits (simulation_experiment.ipynb:762-763)
+    assert np.allclose(out["pred"][:4], [1.025, 1.129, 1.177, 1.106], atol=6e-4), out["pred"][:4]
+    assert np.allclose(out["pred"][-3:], [-0.3236, -0.2804, -0.2439], atol=6e-5), out["pred"][-3:]
+    assert np.allclose(out["pred_err"][:4], [0.2072, 0.1824, 0.1494, 0.0871], atol=6e-5)
+    assert np.allclose(out["pred_err"][-3:], [0.6993, 0.7249, 0.754], atol=6e-4)
+    # univariate kriging of process 1 (cells 13-14): params of process 1 only
+    mod_u = make_model([1.0, 1.5, 0.2, 0.0], n_procs=1)
+    mf_u = make_mf([coords[1]], [values[1]])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out_u = ref_joint(mod_u, mf_u, 0, pcoords, metric=1)
+    assert np.allclose(out_u["pred"][:4], [1.014, 1.091, 1.125, 1.07], atol=6e-4), out_u["pred"][:4]
+    assert np.allclose(out_u["pred"][-3:], [-0.6809, -0.6303, -0.5793], atol=6e-5)
+    assert np.allclose(out_u["pred_err"][:3], [0.2073, 0.1838, 0.1526], atol=6e-5)
+    assert np.allclose(out_u["pred_err"][-3:], [0.7533, 0.7751, 0.7987], atol=6e-5)
+    save("kat_simulation_experiment", params=np.array(SET_KAT), coords0=coords[0], coords1=coords[1],
+         values0=values[0], values1=values[1], pcoords=pcoords, pred=out["pred"], pred_err=out["pred_err"],
+         params_uni=np.array([1.0, 1.5, 0.2, 0.0]), pred_uni=out_u["pred"], pred_err_uni=out_u["pred_err"])
+
+
+def fixture_kv():
+    nus = np.array([0.2, 0.39, 0.5, 0.695, 0.761062, 0.9986, 0.998611, 1.0, 1.3, 1.5, 2.0, 2.2, 2.5,
+                    3.0, 3.4999, 3.499987, 3.5])
+    x = np.concatenate([np.logspace(-8, 3, 111), [1.9999, 2.0, 2.0001, 700.0, 745.0, 800.0]])
+    import scipy.special as sps
+    kv = np.array([sps.kv(nu, x) for nu in nus])
+    # full correlation through the reference function, len_scale = 1 (h plays the role of h/ell)
+    h = np.concatenate([[0.0], np.logspace(-9, 3.2, 123)])
+    rho = np.array([model._matern_correlation(nu, 1.0, h) for nu in nus])
+    rho_l = np.array([model._matern_correlation(nu, 460.0, h * 460.0) for nu in nus])
+    save("kv_grid", nus=nus, x=x, kv=kv, h=h, rho=rho, rho_len460=rho_l)
+
+
+def fixture_cov():
+    rng = np.random.default_rng(101)
+    A = conus_points(rng, 64)
+    B = conus_points(rng, 48)
+    B[:10] = A[:10]  # co-located sites across processes
+    A[20] = A[21]    # bit-identical sites within a process -> nugget off the diagonal
+    G = conus_points(rng, 50)
+    G[:5] = A[:5]    # prediction sites on data sites -> nugget in c0
+    out = dict(A=A, B=B, G=G)
+    out["hav_AB"] = fields.distance_matrix(A, B, fast_dist=True)
+    out["hav_AA"] = fields.distance_matrix(A, A, fast_dist=True)
+    out["euc_AB"] = fields.distance_matrix(A, B, units=None, fast_dist=False)
+    for name, vals in (("A", SET_A), ("B", SET_B), ("R", SET_R), ("S", SET_S)):
+        mod = make_model(vals)
+        mf = make_mf([A, B], [np.zeros(64), np.zeros(48)])
+        P = joint_prediction.Predictor(mod, mf)
+        out[f"Sigma_{name}"] = P._joint_cov()
+        for i in (0, 1):
+            P.i = i
+            out[f"c0_{name}_{i}"] = P._pred_cross_cov(G)
+        out[f"params_{name}"] = np.array(vals, dtype=float)
+    # Euclidean, generic nu, unit square
+    rng = np.random.default_rng(102)
+    U0, U1, UG = rng.random((40, 2)), rng.random((56, 2)), rng.random((30, 2))
+    U1[:7] = U0[:7]
+    mod = make_model(SET_U)
+    mf = make_mf([U0, U1], [np.zeros(40), np.zeros(56)])
+    P = joint_prediction.Predictor(mod, mf, fast_dist=False, dist_units=None)
+    P.i = 0
+    out.update(U0=U0, U1=U1, UG=UG, params_U=np.array(SET_U), Sigma_U=P._joint_cov(), c0_U_0=P._pred_cross_cov(UG))
+    save("cov_blocks", **out)
+
+
+def fixture_solve():
+    out = {}
+    for tag, vals, seed in (("A", SET_A, 201), ("R", SET_R, 202), ("B", SET_B, 203)):
+        rng = np.random.default_rng(seed)
+        n0, n1, m = 210, 190, 120
+        pts = lattice_points(rng, 300, step=0.5)
+        c0 = pts[:n0]
+        c1 = np.vstack([pts[:100], pts[n0:n0 + 90]])  # 100 co-located, 90 not
+        mod = make_model(vals)
+        # values: an exact draw from the model on these sites
+        mf = make_mf([c0, c1], [np.zeros(n0), np.zeros(n1)])
+        P = joint_prediction.Predictor(mod, mf)
+        S = P._joint_cov()
+        z = np.linalg.cholesky(S) @ rng.standard_normal(n0 + n1)
+        mf = make_mf([c0, c1], [z[:n0], z[n0:]])
+        G = np.column_stack([rng.uniform(24, 50, m), rng.uniform(-124, -68, m)])
+        G[:6] = c0[:6]
+        for i in (0, 1):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r = ref_joint(mod, mf, i, G, metric=0, verify=(i == 0))
+            out[f"pred_{tag}_{i}"] = r["pred"]
+            out[f"pred_err_{tag}_{i}"] = r["pred_err"]
+            out[f"verify_warned_{tag}_{i}"] = np.array(r["warned"])
+        out[f"W_{tag}_1"] = r["W"]
+        out.update({f"coords0_{tag}": c0, f"coords1_{tag}": c1, f"values0_{tag}": z[:n0],
+                    f"values1_{tag}": z[n0:], f"pcoords_{tag}": G, f"params_{tag}": np.array(vals, dtype=float)})
+    save("joint_solve", **out)
+
+
+def fixture_npd():
+    """Set S makes Sigma indefinite -> cho_factor raises (src/joint_prediction.py:69, uncaught)."""
+    rng = np.random.default_rng(301)
+    pts = lattice_points(rng, 500, step=0.25)
+    c0, c1 = pts[:260], pts[200:460]
+    mod = make_model(SET_S)
+    mf = make_mf([c0, c1], [np.zeros(260), np.zeros(260)])
+    P = joint_prediction.Predictor(mod, mf)
+    S = P._joint_cov()
+    try:
+        cho_factor(S.copy(), lower=True, check_finite=False)
+        raise SystemExit("expected LinAlgError")
+    except LinAlgError as e:
+        msg = str(e)
+    minor = int(msg.split("-th")[0])
+    lam_min = np.linalg.eigvalsh(S)[0]
+    save("joint_not_pd", coords0=c0, coords1=c1, params=np.array(SET_S), minor=np.array(minor),
+         lam_min=np.array(lam_min), message=np.array(msg))
+
+
+def fixture_loocv():
+    rng = np.random.default_rng(401)
+    pts = lattice_points(rng, 60, step=1.0)
+    c0, c1 = pts[:36], np.vstack([pts[:14], pts[36:58]])
+    mod = make_model(SET_A)
+    mf = make_mf([c0, c1], [np.zeros(36), np.zeros(36)])
+    S = joint_prediction.Predictor(mod, mf)._joint_cov()
+    z = np.linalg.cholesky(S) @ rng.standard_normal(72)
+    mf = make_mf([c0, c1], [z[:36], z[36:]])
+    out = dict(coords0=c0, coords1=c1, values0=z[:36], values1=z[36:], params=np.array(SET_A))
+    for i in (0, 1):
+        pr, pe = [], []
+        for ix in range(36):
+            r = ref_joint(mod, mf, i, mf.fields[i].coords_main[ix], metric=0, cv_ix=ix)
+            pr.append(r["pred"][0])
+            pe.append(r["pred_err"][0])
+        out[f"pred_{i}"] = np.array(pr)
+        out[f"pred_err_{i}"] = np.array(pe)
+    save("joint_loocv", **out)
+
+
+def fixture_local():
+    """point_prediction.Predictor (src/point_prediction.py) incl. empty neighbourhoods,
+    coincident sites and the cv=True rule."""
+    rng = np.random.default_rng(501)
+    pts = lattice_points(rng, 330, step=0.5)
+    c0, c1 = pts[:200], np.vstack([pts[:80], pts[200:320]])
+    out = dict(coords0=c0, coords1=c1)
+    for tag, vals in (("A", SET_A), ("R", SET_R)):
+        mod = make_model(vals)
+        mf = make_mf([c0, c1], [np.zeros(200), np.zeros(200)])
+        S = joint_prediction.Predictor(mod, mf)._joint_cov()
+        z = np.linalg.cholesky(S) @ np.random.default_rng(502).standard_normal(400)
+        mf = make_mf([c0, c1], [z[:200], z[200:]])
+        G = np.column_stack([rng.uniform(20, 60, 90), rng.uniform(-135, -60, 90)])  # some outside
+        G[:5] = c0[:5]
+        G[5] = [10.0, -170.0]  # certainly empty neighbourhood
+        P = point_prediction.Predictor(mod, mf)
+        for i in (0, 1):
+            for md in (300.0, 1000.0):
+                P.i = i
+                P.cv = False
+                c0s = mod.covariance(i, 0, use_nugget=True)[0]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    df = P._predict_chunk(pd.DataFrame(G.copy(), columns=["lat", "lon"]), c0s, md)
+                out[f"pred_{tag}_{i}_{int(md)}"] = df["pred"].values.astype(float)
+                out[f"pred_err_{tag}_{i}_{int(md)}"] = df["pred_err"].values.astype(float)
+        # cross-validation flavour (cv=True; src/point_prediction.py:141-143, 303-346)
+        P.cv = True
+        P.i = 0
+        c0s = mod.covariance(0, 0, use_nugget=True)[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df = P._predict_chunk(pd.DataFrame(c0[:60].copy(), columns=["d1", "d2"]), c0s, 700.0)
+        out[f"cv_pred_{tag}"] = df["pred"].values.astype(float)
+        out[f"cv_pred_err_{tag}"] = df["pred_err"].values.astype(float)
+        out.update({f"values0_{tag}": z[:200], f"values1_{tag}": z[200:], f"pcoords_{tag}": G,
+                    f"params_{tag}": np.array(vals, dtype=float)})
+    save("point_local", **out)
+
+
+def fixture_vario():
+    rng = np.random.default_rng(601)
+    c0, c1 = conus_points(rng, 800), conus_points(rng, 600)
+    c1[:50] = c0[:50]
+    v0 = rng.standard_normal(800) + 0.3
+    v1 = 0.5 * rng.standard_normal(600) - 0.1
+    mf = make_mf([c0, c1], [v0, v1], coords_all=[c0, c1], values_all=[v0, v1])
+    out = dict(coords0=c0, coords1=c1, values0=v0, values1=v1)
+    for kind in ("Semivariogram", "Covariogram"):
+        for md, nb in ((1500.0, 30), (600.0, 12)):
+            cfg = fields.VarioConfig(md, nb, kind=kind)
+            for (i, j) in ((0, 0), (0, 1), (1, 1)):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    df_cloud = mf._variogram_cloud(i, j, cfg)
+                    df_cloud = df_cloud[df_cloud.distance <= cfg.max_dist]
+                    centers, edges = fields._construct_variogram_bins(df_cloud, cfg.n_bins)
+                    df = mf.get_variogram(i, j, cfg)
+                key = f"{kind[:4].lower()}_{int(md)}_{nb}_{i}{j}"
+                out[key + "_centers"] = df["bin_center"].values.astype(float)
+                out[key + "_edges"] = edges
+                out[key + "_means"] = df["bin_mean"].values.astype(float)
+                out[key + "_counts"] = df["bin_count"].values.astype(np.int64)
+    # Euclidean flavour (unit square)
+    rng = np.random.default_rng(602)
+    e0, e1 = rng.random((300, 2)), rng.random((260, 2))
+    w0, w1 = rng.standard_normal(300), rng.standard_normal(260)
+    mf = make_mf([e0, e1], [w0, w1], coords_all=[e0, e1], values_all=[w0, w1])
+    cfg = fields.VarioConfig(0.6, 15, dist_units=None, fast_dist=False)
+    out.update(e0=e0, e1=e1, w0=w0, w1=w1)
+    for (i, j) in ((0, 0), (0, 1), (1, 1)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df = mf.get_variogram(i, j, cfg)
+        key = f"euc_{i}{j}"
+        out[key + "_centers"] = df["bin_center"].values.astype(float)
+        out[key + "_means"] = df["bin_mean"].values.astype(float)
+        out[key + "_counts"] = df["bin_count"].values.astype(np.int64)
+    save("variogram", **out)
+
+
+def fixture_sim():
+    """sim.BivariateRandomField draw on a small grid (src/sim.py:33-54) -- generator parity."""
+    mod = make_model(SET_KAT)
+    grid = sim.CartesianGrid(xcount=13, ycount=11)
+    rf = sim.BivariateRandomField(mod, grid, seed=7)
+    save("sim_field", params=np.array(SET_KAT), coords=grid.coords.values, cmat=rf.cmat,
+         field0=rf.fields[0]["value"].values, field1=rf.fields[1]["value"].values,
+         noise=np.random.default_rng(7).standard_normal(2 * grid.count))
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, fn in list(globals().items()):
+        if name.startswith("fixture_") and (not only or name[8:] in only):
+            fn()
