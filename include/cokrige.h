@@ -1,0 +1,143 @@
+/* cokrige.h -- C ABI of libcokrige_hip.so, the MI355X (gfx950) numeric core of
+ * the bivariate Matern cokriging predictor.
+ *
+ * The reference (91Mrwu/sif-xco2-cokriging) is pure Python and has no FFI of its
+ * own; its drop-in boundary is the Python class API
+ *     joint_prediction.Predictor   (src/joint_prediction.py:13-92)
+ *     point_prediction.Predictor   (src/point_prediction.py:21-96)
+ *     MultivariateMatern.covariance/cross_covariance (src/model.py:193-207)
+ *     fields.distance_matrix       (src/fields.py:318-342)
+ *     MultiField.empirical_variograms (src/fields.py:192-252)
+ * Each entry point below names the reference lines whose arithmetic it
+ * replaces.  The Python host layer in sif-xco2-cokriging_amd/ binds these
+ * symbols with ctypes (see INTEGRATION.md for the stub a maintainer of the
+ * reference would add).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = error (text from
+ *     ck_last_error(), thread local).  Numerical failure of the Cholesky
+ *     factorisation is NOT an error code: it is reported LAPACK-style through
+ *     `info` (1-based index of the first non-positive pivot, 0 = success).
+ *   - "host" pointers are caller-owned, C-contiguous float64 (numpy) buffers,
+ *     read or written during the call and never retained.
+ *   - "dev" pointers are device addresses (e.g. torch.Tensor.data_ptr()).
+ *   - coordinates are rows [lat, lon] in degrees for CK_METRIC_HAVERSINE
+ *     (fast_dist=True, km) or [x, y] for CK_METRIC_EUCLID (src/fields.py:326-342).
+ *   - a handle owns one GPU and one HIP stream; it is not thread-safe, distinct
+ *     handles may be used from distinct threads.
+ */
+#ifndef COKRIGE_H
+#define COKRIGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ck_handle ck_handle;
+
+#define CK_METRIC_HAVERSINE 0 /* fast_dist=True : 6371 km * haversine (src/fields.py:332-336) */
+#define CK_METRIC_EUCLID 1    /* fast_dist=False, units=None : Euclidean (src/fields.py:340-342) */
+
+#define CK_APPLY_SIGMA 1 /* ck_panel_apply: update the local trailing block columns of Sigma */
+#define CK_APPLY_AUX 2   /* ck_panel_apply: forward-substitute / update the right-hand-side rows */
+
+/* ---- library ------------------------------------------------------------- */
+const char* ck_last_error(void);
+int ck_version(void);
+int ck_device_count(int* n);
+
+/* ---- handle ---------------------------------------------------------------- */
+int ck_create(int device_id, ck_handle** out);
+int ck_destroy(ck_handle* h);
+/* Use an external HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the handle's own stream. */
+int ck_set_stream(ck_handle* h, void* hip_stream);
+/* Let the caller provide all device storage (e.g. one torch uint8 tensor), so a
+ * host framework owns the memory and can run collectives on slices of it.
+ * Without an arena the library allocates with hipMalloc.  Must precede ck_set_data. */
+int ck_set_arena(ck_handle* h, void* dev_base, int64_t nbytes);
+int ck_synchronize(ck_handle* h);
+
+/* ---- model and data ------------------------------------------------------- */
+/* Matern parameters in the reference's order (src/model.py:122-130,145-152):
+ * sigma[n_procs], nu[3] = (11, 12, 22), len_scale[3] = (11, 12, 22),
+ * nugget[n_procs], rho12.  n_procs = 1: nu[0], len_scale[0] only. */
+int ck_set_model(ck_handle* h, int n_procs, const double* sigma, const double* nu, const double* len_scale,
+                 const double* nugget, double rho12);
+int ck_set_metric(ck_handle* h, int metric);
+/* 1-D block-column-cyclic ownership of Sigma over `world` processes (one GPU
+ * each); prediction points are sharded by the caller.  Default (0, 1). */
+int ck_set_partition(ck_handle* h, int rank, int world);
+/* Observation sites of process k: coords (n_k x 2), values (n_k): Field.coords_main /
+ * Field.values_main (src/fields.py:78-81, consumed at src/joint_prediction.py:53-55,106-111,130-132). */
+int ck_set_data(ck_handle* h, int k, const double* coords_host, const double* values_host, int64_t n_k);
+
+/* ---- element-wise parity surface (tests, and the model/fields mirrors) ----- */
+/* fields.distance_matrix(A, B) (src/fields.py:318-342) -> out (a x b). */
+int ck_distance_dense(ck_handle* h, const double* A_host, int64_t a, const double* B_host, int64_t b,
+                      double* out_host);
+/* covariance(i, D(A,B), use_nugget) if i == j else cross_covariance(i, j, D(A,B))
+ * (src/model.py:193-207 on src/fields.py:318-342) -> out (a x b). */
+int ck_cov_dense(ck_handle* h, int i, int j, const double* A_host, int64_t a, const double* B_host, int64_t b,
+                 int use_nugget, double* out_host);
+/* the same at given lags h[n] (MultivariateMatern.covariance / cross_covariance on an array). */
+int ck_cov_lags(ck_handle* h, int i, int j, const double* lags_host, int64_t n, int use_nugget, double* out_host);
+
+/* ---- joint (global) cokriging: src/joint_prediction.py:35-153 --------------- */
+/* K1: assemble the lower block triangle of Sigma = [[C11, C12], [C12^T, C22]] for the
+ * locally owned block columns (Predictor._joint_cov, src/joint_prediction.py:124-153). */
+int ck_assemble_joint(ck_handle* h);
+/* K3: in-place blocked Cholesky Sigma = L L^T (cho_factor(lower=True), src/joint_prediction.py:69).
+ * info = 0, or the 1-based order of the leading minor that is not positive definite
+ * (scipy raises LinAlgError with that number).  Single-process form; for world > 1 drive
+ * ck_panel_factor / ck_panel_apply from the host with a broadcast in between. */
+int ck_factor(ck_handle* h, int64_t* info);
+/* K2 + K4: prediction and standard error of process i at pcoords (m x 2):
+ * c0 (Predictor._pred_cross_cov, :104-122), forward substitution V = L^-1 [c0 | z],
+ * pred = V^T y, pred_err = nan_to_num(sqrt(sigma_i^2 + nugget_i - |V_k|^2)) (:68-78).
+ * Needs ck_factor; may be called repeatedly. */
+int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host);
+
+/* ---- step-wise form (multi-GPU, fused solve) ------------------------------ */
+int ck_num_panels(ck_handle* h, int* n_panels, int* panel_width, int64_t* n_padded);
+int ck_panel_owner(ck_handle* h, int K, int* owner_rank);
+/* Right-hand-side rows for prediction of process i at pcoords (this rank's shard):
+ * assembles c0^T rows and the data row z^T (K2). */
+int ck_aux_begin(ck_handle* h, int i, const double* pcoords_host, int64_t m);
+/* Factor block column K in place (owner only): diagonal blocks, panel solve. */
+int ck_panel_factor(ck_handle* h, int K);
+/* Device address / size of the packed panel K: the owner's storage, or this rank's
+ * receive buffer (the host broadcasts owner -> all between factor and apply). */
+int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nbytes);
+/* Apply panel K to the local trailing block columns (CK_APPLY_SIGMA) and/or to the
+ * right-hand-side rows (CK_APPLY_AUX). */
+int ck_panel_apply(ck_handle* h, int K, int what);
+/* pred / pred_err of the local shard after all panels were applied to the aux rows. */
+int ck_aux_finish(ck_handle* h, double* pred_host, double* pred_err_host);
+/* info flag of the factorisation so far (synchronises). */
+int ck_factor_info(ck_handle* h, int64_t* info);
+
+/* ---- diagnostics ------------------------------------------------------------- */
+/* Copy the locally owned part of Sigma / L back as a dense (N x N) lower triangle
+ * (upper triangle zero-filled); small N only (tests). */
+int ck_debug_get_lower(ck_handle* h, double* out_host, int64_t n);
+/* Raw lane/register -> (row, col) map of v_mfma_f64_16x16x4_f64: out[64*4*3] ints (row, col, k-map check). */
+int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
+/* Stage timings of the last calls in milliseconds (HIP events):
+ * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
+ * [5] trailing-update GEMM launches total inside factor, [6] number of those launches. */
+int ck_timings(ck_handle* h, double* out, int n);
+/* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events. */
+int ck_set_option(ck_handle* h, const char* name, int64_t value);
+/* Plain C -= A B^T on device buffers through the MFMA kernel (tests / microbenchmarks).
+ * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), all row-major device doubles;
+ * M % 256 == 0, N % 64 == 0, K % 16 == 0.  lower != 0 skips tiles strictly above the diagonal. */
+int ck_dev_gemm_nt(ck_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda, const double* B_dev,
+                   int64_t ldb, int64_t M, int64_t N, int64_t K, int lower);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COKRIGE_H */

@@ -1,0 +1,674 @@
+// ck_api.hip -- the C ABI of libcokrige_hip.so (include/cokrige.h): handle, device storage,
+// and the host-side drivers of the blocked algorithms.
+//
+// Storage (all FP64, row-major):
+//   Sigma / L   lower block triangle in packed block columns ("panels") of width NB = 512:
+//               panel K holds rows [K*NB, Npad) x cols [K*NB, (K+1)*NB), ld = NB.  With
+//               world > 1 a process owns the panels K % world == rank.  Npad = N rounded up
+//               to NB; padded rows/cols carry an identity so no kernel needs edge code.
+//   aux         the right-hand-side rows c0^T (one row per prediction site) and z^T, in the
+//               same panel format: aux panel K is mpad x NB at aux + K*mpad*NB.
+// Algorithm: right-looking blocked Cholesky on the tall matrix [Sigma; c0^T; z^T]
+// (the forward substitution of cho_solve IS the panel step applied to the extra rows),
+// two-level blocking NB = 512 / IB = 64, trailing updates on FP64 MFMA.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cokrige.h"
+#include "ck_internal.h"
+#include "ck_model.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +   \
+                        std::to_string(__LINE__) + ")");                                          \
+    } while (0)
+#define CHKH(h)                       \
+    if (!(h)) return fail("null handle"); \
+    HIPCHK(hipSetDevice((h)->device))
+
+struct EvPair {
+    hipEvent_t a, b;
+};
+
+struct ck_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // arena
+    char* arena = nullptr;
+    int64_t arena_size = 0, arena_used = 0;
+    std::vector<void*> owned;   // hipMalloc'ed blocks (no arena)
+    // model
+    int n_procs = 0;
+    int metric = CK_METRIC_HAVERSINE;
+    CkMatern blk[3];
+    CkMatern* d_blk = nullptr;
+    bool model_set = false;
+    // partition
+    int rank = 0, world = 1;
+    // data
+    std::vector<double> h_coords[2], h_values[2];
+    int64_t n[2] = {0, 0};
+    bool data_set[2] = {false, false};
+    int64_t N = 0, Npad = 0;
+    int nK = 0;
+    bool layout_ready = false;
+    double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *z = nullptr;   // stacked sites / values (Npad)
+    std::vector<double*> sig;    // per panel; nullptr if not owned
+    double** d_sigptr = nullptr;
+    double* recv[2] = {nullptr, nullptr};   // receive buffers for remote panels (world > 1)
+    long long* d_info = nullptr;
+    bool assembled = false, factored = false;
+    // aux
+    int i_pred = 0;
+    int64_t m = 0, mpad = 0, aux_cap = 0;   // aux_cap in doubles
+    double* aux = nullptr;
+    double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+    int64_t p_cap = 0;
+    double *d_pred = nullptr, *d_err = nullptr;
+    double* d_pcoords = nullptr;
+    // scratch for dense calls
+    // timings
+    double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool time_gemm = false;
+    std::vector<EvPair> gemm_ev;
+    size_t gemm_ev_used = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" const char* ck_last_error(void) { return g_err.c_str(); }
+extern "C" int ck_version(void) { return 100; }
+extern "C" int ck_device_count(int* n) {
+    HIPCHK(hipGetDeviceCount(n));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// memory
+// ---------------------------------------------------------------------------------------
+static int dev_alloc(ck_handle* h, void** out, int64_t bytes) {
+    bytes = (bytes + 255) & ~(int64_t)255;
+    if (h->arena) {
+        if (h->arena_used + bytes > h->arena_size)
+            return fail("arena too small: need " + std::to_string(h->arena_used + bytes) + " bytes, have " +
+                        std::to_string(h->arena_size));
+        *out = h->arena + h->arena_used;
+        h->arena_used += bytes;
+        return 0;
+    }
+    HIPCHK(hipMalloc(out, (size_t)bytes));
+    h->owned.push_back(*out);
+    return 0;
+}
+static void dev_free_one(ck_handle* h, void* p) {
+    if (!p || h->arena) return;
+    for (size_t i = 0; i < h->owned.size(); ++i)
+        if (h->owned[i] == p) {
+            (void)hipFree(p);
+            h->owned.erase(h->owned.begin() + i);
+            return;
+        }
+}
+
+extern "C" int ck_create(int device_id, ck_handle** out) {
+    if (!out) return fail("null out");
+    int nd = 0;
+    HIPCHK(hipGetDeviceCount(&nd));
+    if (nd <= 0) return fail("no HIP device visible: libcokrige_hip needs an MI355X (gfx950)");
+    if (device_id < 0 || device_id >= nd) return fail("bad device id");
+    HIPCHK(hipSetDevice(device_id));
+    ck_handle* h = new ck_handle();
+    h->device = device_id;
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipMalloc((void**)&h->d_blk, 3 * sizeof(CkMatern)));
+    HIPCHK(hipMalloc((void**)&h->d_info, sizeof(long long)));
+    HIPCHK(hipMemset(h->d_info, 0, sizeof(long long)));
+    *out = h;
+    return 0;
+}
+
+extern "C" int ck_destroy(ck_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->owned) (void)hipFree(p);
+    (void)hipFree(h->d_blk);
+    (void)hipFree(h->d_info);
+    for (auto& e : h->gemm_ev) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int ck_set_stream(ck_handle* h, void* hip_stream) {
+    CHKH(h);
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return 0;
+}
+
+extern "C" int ck_set_arena(ck_handle* h, void* dev_base, int64_t nbytes) {
+    CHKH(h);
+    if (h->layout_ready || !h->owned.empty()) return fail("ck_set_arena must precede any allocation");
+    if (((uintptr_t)dev_base & 255) != 0) return fail("arena base must be 256-byte aligned");
+    h->arena = (char*)dev_base;
+    h->arena_size = nbytes;
+    h->arena_used = 0;
+    return 0;
+}
+
+extern "C" int ck_synchronize(ck_handle* h) {
+    CHKH(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// model / data
+// ---------------------------------------------------------------------------------------
+extern "C" int ck_set_model(ck_handle* h, int n_procs, const double* sigma, const double* nu, const double* len_scale,
+                            const double* nugget, double rho12) {
+    CHKH(h);
+    if (n_procs != 1 && n_procs != 2) return fail("n_procs must be 1 or 2");
+    if (!sigma || !nu || !len_scale || !nugget) return fail("null parameter array");
+    const int nb = n_procs == 1 ? 1 : 3;
+    for (int k = 0; k < nb; ++k)
+        if (!(nu[k] > 0.0) || !(len_scale[k] > 0.0)) return fail("nu and len_scale must be positive");
+    ck_model_prepare(n_procs, sigma, nu, len_scale, nugget, rho12, h->blk);
+    h->n_procs = n_procs;
+    HIPCHK(hipMemcpyAsync(h->d_blk, h->blk, 3 * sizeof(CkMatern), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->model_set = true;
+    h->assembled = h->factored = false;
+    return 0;
+}
+
+extern "C" int ck_set_metric(ck_handle* h, int metric) {
+    CHKH(h);
+    if (metric != CK_METRIC_HAVERSINE && metric != CK_METRIC_EUCLID) return fail("unknown metric");
+    if (metric != h->metric) {
+        h->metric = metric;
+        h->layout_ready = false;   // site transforms depend on the metric
+        h->assembled = h->factored = false;
+    }
+    return 0;
+}
+
+extern "C" int ck_set_partition(ck_handle* h, int rank, int world) {
+    CHKH(h);
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad partition");
+    if (h->layout_ready) return fail("ck_set_partition must precede ck_assemble_joint");
+    h->rank = rank;
+    h->world = world;
+    return 0;
+}
+
+extern "C" int ck_set_data(ck_handle* h, int k, const double* coords, const double* values, int64_t n_k) {
+    CHKH(h);
+    if (k < 0 || k > 1) return fail("process index must be 0 or 1");
+    if (n_k < 0 || (n_k > 0 && (!coords || !values))) return fail("bad data arrays");
+    if (h->layout_ready) return fail("data already laid out on the device; create a new handle to change it");
+    h->h_coords[k].assign(coords, coords + 2 * n_k);
+    h->h_values[k].assign(values, values + n_k);
+    h->n[k] = n_k;
+    h->data_set[k] = true;
+    return 0;
+}
+
+static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Decide the padded layout, upload sites / values, allocate the owned panels.
+static int ensure_layout(ck_handle* h) {
+    if (h->layout_ready) return 0;
+    if (!h->model_set) return fail("ck_set_model has not been called");
+    for (int k = 0; k < h->n_procs; ++k)
+        if (!h->data_set[k]) return fail("ck_set_data missing for process " + std::to_string(k));
+    const int64_t n0 = h->n[0], n1 = h->n_procs == 2 ? h->n[1] : 0;
+    h->N = n0 + n1;
+    if (h->N <= 0) return fail("no observations");
+    h->Npad = roundup(h->N, CK_NB);
+    h->nK = (int)(h->Npad / CK_NB);
+    const int64_t Np = h->Npad;
+    if (!h->s0) {
+        if (dev_alloc(h, (void**)&h->s0, Np * 8) || dev_alloc(h, (void**)&h->s1, Np * 8) ||
+            dev_alloc(h, (void**)&h->s2, Np * 8) || dev_alloc(h, (void**)&h->z, Np * 8))
+            return -1;
+    }
+    // stage coords -> device, transform
+    std::vector<double> hc(2 * Np, 0.0), hz(Np, 0.0);
+    memcpy(hc.data(), h->h_coords[0].data(), 2 * n0 * 8);
+    memcpy(hz.data(), h->h_values[0].data(), n0 * 8);
+    if (n1) {
+        memcpy(hc.data() + 2 * n0, h->h_coords[1].data(), 2 * n1 * 8);
+        memcpy(hz.data() + n0, h->h_values[1].data(), n1 * 8);
+    }
+    double* d_tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tmp, 2 * Np * 8));
+    HIPCHK(hipMemcpyAsync(d_tmp, hc.data(), 2 * Np * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->z, hz.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_prep_sites(h->stream, d_tmp, Np, h->metric, h->s0, h->s1, h->s2);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d_tmp));
+    // panels
+    if (h->sig.empty()) {
+        h->sig.assign(h->nK, nullptr);
+        for (int K = h->rank; K < h->nK; K += h->world) {
+            const int64_t rows = Np - (int64_t)K * CK_NB;
+            if (dev_alloc(h, (void**)&h->sig[K], rows * CK_NB * 8)) return -1;
+        }
+        if (dev_alloc(h, (void**)&h->d_sigptr, (int64_t)h->nK * sizeof(double*))) return -1;
+        HIPCHK(hipMemcpy(h->d_sigptr, h->sig.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
+        if (h->world > 1) {
+            for (int b = 0; b < 2; ++b)
+                if (dev_alloc(h, (void**)&h->recv[b], Np * CK_NB * 8)) return -1;
+        }
+    }
+    h->layout_ready = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// element-wise parity surface
+// ---------------------------------------------------------------------------------------
+static int blk_index(ck_handle* h, int i, int j, int* idx) {
+    if (!h->model_set) return fail("ck_set_model has not been called");
+    if (i < 0 || j < 0 || i >= h->n_procs || j >= h->n_procs) return fail("process index out of range");
+    *idx = i + j;
+    return 0;
+}
+
+static int dense_common(ck_handle* h, int bidx, int add_nugget, int mode, const double* A, int64_t a, const double* B,
+                        int64_t b, double* out) {
+    if (a <= 0 || b <= 0) return 0;
+    double *dA = nullptr, *dB = nullptr, *dO = nullptr, *ta = nullptr, *tb = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, 2 * a * 8));
+    HIPCHK(hipMalloc((void**)&dB, 2 * b * 8));
+    HIPCHK(hipMalloc((void**)&ta, 3 * a * 8));
+    HIPCHK(hipMalloc((void**)&tb, 3 * b * 8));
+    HIPCHK(hipMalloc((void**)&dO, a * b * 8));
+    HIPCHK(hipMemcpyAsync(dA, A, 2 * a * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dB, B, 2 * b * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_prep_sites(h->stream, dA, a, h->metric, ta, ta + a, ta + 2 * a);
+    ck_launch_prep_sites(h->stream, dB, b, h->metric, tb, tb + b, tb + 2 * b);
+    ck_launch_cov_dense(h->stream, h->d_blk + bidx, h->metric, add_nugget, mode, ta, ta + a, ta + 2 * a, a, tb, tb + b,
+                        tb + 2 * b, b, dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, a * b * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(dA);
+    (void)hipFree(dB);
+    (void)hipFree(ta);
+    (void)hipFree(tb);
+    (void)hipFree(dO);
+    return 0;
+}
+
+extern "C" int ck_distance_dense(ck_handle* h, const double* A, int64_t a, const double* B, int64_t b, double* out) {
+    CHKH(h);
+    return dense_common(h, 0, 0, 1, A, a, B, b, out);
+}
+
+extern "C" int ck_cov_dense(ck_handle* h, int i, int j, const double* A, int64_t a, const double* B, int64_t b,
+                            int use_nugget, double* out) {
+    CHKH(h);
+    int bidx;
+    if (blk_index(h, i, j, &bidx)) return -1;
+    return dense_common(h, bidx, (i == j) && use_nugget, 0, A, a, B, b, out);
+}
+
+extern "C" int ck_cov_lags(ck_handle* h, int i, int j, const double* lags, int64_t n, int use_nugget, double* out) {
+    CHKH(h);
+    int bidx;
+    if (blk_index(h, i, j, &bidx)) return -1;
+    if (n <= 0) return 0;
+    double *dl = nullptr, *dO = nullptr;
+    HIPCHK(hipMalloc((void**)&dl, n * 8));
+    HIPCHK(hipMalloc((void**)&dO, n * 8));
+    HIPCHK(hipMemcpyAsync(dl, lags, n * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_cov_lags(h->stream, h->d_blk + bidx, (i == j) && use_nugget, dl, n, dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(dl);
+    (void)hipFree(dO);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// joint path
+// ---------------------------------------------------------------------------------------
+extern "C" int ck_assemble_joint(ck_handle* h) {
+    CHKH(h);
+    if (ensure_layout(h)) return -1;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int K = h->rank; K < h->nK; K += h->world) {
+        const int64_t row0 = (int64_t)K * CK_NB;
+        ck_launch_assemble_sigma_panel(h->stream, h->d_blk, h->metric, h->s0, h->s1, h->s2, h->n[0], h->N, row0,
+                                       h->Npad - row0, row0, h->sig[K]);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(long long), h->stream));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[0] = ms;
+    h->assembled = true;
+    h->factored = false;
+    return 0;
+}
+
+extern "C" int ck_num_panels(ck_handle* h, int* n_panels, int* panel_width, int64_t* n_padded) {
+    CHKH(h);
+    if (ensure_layout(h)) return -1;
+    if (n_panels) *n_panels = h->nK;
+    if (panel_width) *panel_width = CK_NB;
+    if (n_padded) *n_padded = h->Npad;
+    return 0;
+}
+
+extern "C" int ck_panel_owner(ck_handle* h, int K, int* owner_rank) {
+    CHKH(h);
+    if (K < 0) return fail("bad panel index");
+    *owner_rank = K % h->world;
+    return 0;
+}
+
+static const double* panel_src(ck_handle* h, int K) { return h->sig[K] ? h->sig[K] : h->recv[K & 1]; }
+
+extern "C" int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nbytes) {
+    CHKH(h);
+    if (ensure_layout(h)) return -1;
+    if (K < 0 || K >= h->nK) return fail("bad panel index");
+    *dev_ptr = (void*)panel_src(h, K);
+    *nbytes = (h->Npad - (int64_t)K * CK_NB) * CK_NB * 8;
+    return 0;
+}
+
+static void gemm_timed_begin(ck_handle* h) {
+    if (!h->time_gemm) return;
+    if (h->gemm_ev_used == h->gemm_ev.size()) {
+        EvPair e;
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+        h->gemm_ev.push_back(e);
+    }
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].a, h->stream);
+}
+static void gemm_timed_end(ck_handle* h) {
+    if (!h->time_gemm) return;
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].b, h->stream);
+    h->gemm_ev_used++;
+}
+
+extern "C" int ck_panel_factor(ck_handle* h, int K) {
+    CHKH(h);
+    if (!h->assembled) return fail("ck_assemble_joint has not been called");
+    if (K < 0 || K >= h->nK) return fail("bad panel index");
+    double* P = h->sig[K];
+    if (!P) return fail("panel " + std::to_string(K) + " is not owned by this rank");
+    const int64_t R = h->Npad - (int64_t)K * CK_NB;
+    for (int q = 0; q < CK_NB / CK_IB; ++q) {
+        double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
+        ck_launch_potrf64(h->stream, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info);
+        const int64_t r1 = (int64_t)(q + 1) * CK_IB;
+        ck_launch_trsm64(h->stream, P + r1 * CK_NB + q * CK_IB, CK_NB, R - r1, diag, CK_NB);
+        const int64_t ncols = CK_NB - r1;
+        if (ncols > 0) {
+            const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
+            ck_launch_gemm_nt(h->stream, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
+                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ck_panel_apply(ck_handle* h, int K, int what) {
+    CHKH(h);
+    if (K < 0 || K >= h->nK) return fail("bad panel index");
+    const double* P = panel_src(h, K);
+    if (what & CK_APPLY_SIGMA) {
+        // first owned J > K
+        int J0 = K + 1;
+        while (J0 < h->nK && (J0 % h->world) != h->rank) ++J0;
+        if (J0 < h->nK) {
+            const int nJ = (h->nK - 1 - J0) / h->world + 1;
+            gemm_timed_begin(h);
+            ck_launch_syrk_panels(h->stream, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
+            gemm_timed_end(h);
+        }
+    }
+    if ((what & CK_APPLY_AUX) && h->mpad > 0) {
+        double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
+        for (int q = 0; q < CK_NB / CK_IB; ++q) {
+            const double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
+            ck_launch_trsm64(h->stream, X + q * CK_IB, CK_NB, h->mpad, diag, CK_NB);
+            const int64_t r1 = (int64_t)(q + 1) * CK_IB;
+            const int64_t ncols = CK_NB - r1;
+            if (ncols > 0)
+                ck_launch_gemm_nt(h->stream, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB,
+                                  h->mpad, ncols, CK_IB, 0, 0, 1, 0, 0, 0);
+        }
+        const int nJ = h->nK - 1 - K;
+        if (nJ > 0) {
+            gemm_timed_begin(h);
+            // aux[J] -= aux[K] * P[(J-K)*NB .. , :]^T for all J > K, batched over J
+            ck_launch_gemm_nt(h->stream, X + h->mpad * CK_NB, CK_NB, X, CK_NB, P + (int64_t)CK_NB * CK_NB, CK_NB,
+                              h->mpad, CK_NB, CK_NB, 0, 0, nJ, h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
+            gemm_timed_end(h);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
+    CHKH(h);
+    long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // a pivot inside the identity padding cannot fail; clamp defensively
+    *info = (int64_t)v;
+    return 0;
+}
+
+extern "C" int ck_factor(ck_handle* h, int64_t* info) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_factor is the single-process form; drive ck_panel_* for world > 1");
+    if (!h->assembled) return fail("ck_assemble_joint has not been called");
+    if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
+    h->gemm_ev_used = 0;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int K = 0; K < h->nK; ++K) {
+        if (ck_panel_factor(h, K)) return -1;
+        if (ck_panel_apply(h, K, CK_APPLY_SIGMA)) return -1;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (ck_factor_info(h, info)) return -1;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[1] = ms;
+    if (h->time_gemm) {
+        double tot = 0;
+        for (size_t e = 0; e < h->gemm_ev_used; ++e) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, h->gemm_ev[e].a, h->gemm_ev[e].b);
+            tot += t;
+        }
+        h->t_ms[5] = tot;
+        h->t_ms[6] = (double)h->gemm_ev_used;
+    }
+    h->factored = true;
+    return 0;
+}
+
+extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t m) {
+    CHKH(h);
+    if (ensure_layout(h)) return -1;
+    if (i < 0 || i >= h->n_procs) return fail("process index out of range");
+    if (m < 0 || (m > 0 && !pcoords)) return fail("bad pcoords");
+    const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
+    const int64_t need = mpad * h->Npad;
+    if (need > h->aux_cap) {
+        dev_free_one(h, h->aux);
+        h->aux = nullptr;
+        if (dev_alloc(h, (void**)&h->aux, need * 8)) return -1;
+        h->aux_cap = need;
+    }
+    if (mpad > h->p_cap) {
+        dev_free_one(h, h->p0);
+        dev_free_one(h, h->d_pcoords);
+        dev_free_one(h, h->d_pred);
+        if (dev_alloc(h, (void**)&h->p0, 3 * mpad * 8)) return -1;
+        if (dev_alloc(h, (void**)&h->d_pcoords, 2 * mpad * 8)) return -1;
+        if (dev_alloc(h, (void**)&h->d_pred, 2 * mpad * 8)) return -1;
+        h->p_cap = mpad;
+    }
+    h->p1 = h->p0 + mpad;
+    h->p2 = h->p0 + 2 * mpad;
+    h->d_err = h->d_pred + mpad;
+    h->i_pred = i;
+    h->m = m;
+    h->mpad = mpad;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
+    if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2);
+    for (int K = 0; K < h->nK; ++K)
+        ck_launch_assemble_aux_panel(h->stream, h->d_blk, h->metric, i, h->p0, h->p1, h->p2, m, mpad, h->s0, h->s1,
+                                     h->s2, h->z, h->n[0], h->N, (int64_t)K * CK_NB,
+                                     h->aux + (int64_t)K * mpad * CK_NB);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));   // pcoords is caller memory: do not return before the copy is done
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[2] = ms;
+    return 0;
+}
+
+extern "C" int ck_aux_finish(ck_handle* h, double* pred, double* pred_err) {
+    CHKH(h);
+    if (h->mpad <= 0) return fail("ck_aux_begin has not been called");
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    const double c0 = h->blk[2 * h->i_pred].amp + h->blk[2 * h->i_pred].nugget;   // sigma_i^2 + nugget_i (model.py:194-196 at h = 0)
+    ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, h->m, h->m, c0, h->d_pred, h->d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (h->m > 0) {
+        HIPCHK(hipMemcpyAsync(pred, h->d_pred, h->m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pred_err, h->d_err, h->m * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[4] = ms;
+    return 0;
+}
+
+extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m, double* pred, double* pred_err) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_predict is the single-process form");
+    if (!h->factored) return fail("ck_factor has not been called");
+    if (ck_aux_begin(h, i, pcoords, m)) return -1;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int K = 0; K < h->nK; ++K)
+        if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    HIPCHK(hipEventRecord(e1, h->stream));
+    if (ck_aux_finish(h, pred, pred_err)) return -1;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    h->t_ms[3] = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------------------
+extern "C" int ck_debug_get_lower(ck_handle* h, double* out, int64_t n) {
+    CHKH(h);
+    if (!h->assembled) return fail("nothing assembled");
+    if (n != h->N) return fail("n must equal the number of observations");
+    std::vector<double> buf;
+    memset(out, 0, (size_t)n * n * 8);
+    for (int K = 0; K < h->nK; ++K) {
+        if (!h->sig[K]) continue;
+        const int64_t rows = h->Npad - (int64_t)K * CK_NB;
+        buf.resize(rows * CK_NB);
+        HIPCHK(hipMemcpyAsync(buf.data(), h->sig[K], rows * CK_NB * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t r = 0; r < rows; ++r) {
+            const int64_t gr = (int64_t)K * CK_NB + r;
+            if (gr >= n) break;
+            for (int64_t c = 0; c < CK_NB; ++c) {
+                const int64_t gc = (int64_t)K * CK_NB + c;
+                if (gc >= n || gc > gr) break;
+                out[gr * n + gc] = buf[r * CK_NB + c];
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
+    CHKH(h);
+    int32_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 64 * 4 * 3 * sizeof(int32_t)));
+    ck_launch_mfma_probe(h->stream, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 64 * 4 * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(d);
+    return 0;
+}
+
+extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
+    CHKH(h);
+    if (!name) return fail("null option name");
+    if (!strcmp(name, "time_gemm")) {
+        h->time_gemm = value != 0;
+        return 0;
+    }
+    return fail(std::string("unknown option ") + name);
+}
+
+extern "C" int ck_timings(ck_handle* h, double* out, int n) {
+    CHKH(h);
+    for (int k = 0; k < n && k < 8; ++k) out[k] = h->t_ms[k];
+    return 0;
+}
+
+extern "C" int ck_dev_gemm_nt(ck_handle* h, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                              int64_t ldb, int64_t M, int64_t N, int64_t K, int lower) {
+    CHKH(h);
+    if (M % CK_BM || N % 64 || K % 16) return fail("ck_dev_gemm_nt: M % 256, N % 64, K % 16 must be 0");
+    ck_launch_gemm_nt(h->stream, C, ldc, A, lda, B, ldb, M, N, K, lower, 0, 1, 0, 0, 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

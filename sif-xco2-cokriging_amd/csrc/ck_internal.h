@@ -1,0 +1,58 @@
+// ck_internal.h -- launch wrappers shared between the translation units of
+// libcokrige_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ck_math.h"
+
+#define CK_NB 512   // outer block column width (panel width)
+#define CK_IB 64    // inner block (diagonal factor / row solves)
+#define CK_BM 256   // GEMM tile rows
+#define CK_AUX_ALIGN 256
+
+// ---- covariance assembly (ck_cov.hip) ---------------------------------------
+// per-site transform: degrees -> (lat_rad, lon_rad, cos lat) | (x, y, 0)
+void ck_launch_prep_sites(hipStream_t s, const double* coords, int64_t n, int metric, double* c0, double* c1,
+                          double* c2);
+// One block column of Sigma: rows [row0, row0 + nrows) x cols [col0, col0 + CK_NB), ld = CK_NB.
+// Sites are the stacked data sites (n0 of process 0, then N - n0 of process 1); entries with a
+// padded index (>= N) form an identity.
+void ck_launch_assemble_sigma_panel(hipStream_t s, const CkMatern* blk, int metric, const double* s0,
+                                    const double* s1, const double* s2, int64_t n0, int64_t N, int64_t row0,
+                                    int64_t nrows, int64_t col0, double* out);
+// One block column of the right-hand-side rows: rows = prediction sites p in [0, m) (row m = data
+// values z, rows > m zero), cols = stacked data sites [col0, col0 + CK_NB).
+void ck_launch_assemble_aux_panel(hipStream_t s, const CkMatern* blk, int metric, int i_pred, const double* p0,
+                                  const double* p1, const double* p2, int64_t m, int64_t mpad, const double* s0,
+                                  const double* s1, const double* s2, const double* z, int64_t n0, int64_t N,
+                                  int64_t col0, double* out);
+// dense a x b block for one (i, j) Matern block; mode 0 = covariance, 1 = distance only
+void ck_launch_cov_dense(hipStream_t s, const CkMatern* blk_ij, int metric, int add_nugget, int mode,
+                         const double* a0, const double* a1, const double* a2, int64_t a, const double* b0,
+                         const double* b1, const double* b2, int64_t b, double* out);
+void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, const double* lags, int64_t n,
+                        double* out);
+
+// ---- dense linear algebra (ck_la.hip) ----------------------------------------
+// C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T on FP64 MFMA.
+// M % 256 == 0, N % 64 == 0, K % 16 == 0.  lower: skip tiles whose rows are all above the
+// diagonal  row + diag_off == col.
+// batch > 1 repeats the product over blockIdx.y with element strides sC / sA / sB.
+void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
+                       int64_t sC, int64_t sA, int64_t sB);
+// Cholesky trailing update of every owned block column J = J0 + y * Jstep (y < nJ) by panel K
+// (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
+void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
+                           int nJ, int64_t Npad);
+// In-place Cholesky of the 64 x 64 diagonal block at A (ld); info_dev gets global_index0 + j + 1 of
+// the first non-positive pivot (only if still 0).
+void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev);
+// X L^T = A in place for `nrows` rows of A (ld), 64 columns; L (64 x 64 lower, ldl).  nrows % 64 == 0.
+void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl);
+// pred[p] = sum_c X[p][c] y[c];  err[p] = nan_to_num(sqrt(c0 - sum_c X[p][c]^2)); X rows live in
+// n_panels panels of width CK_NB at aux + K * mpad * CK_NB; y is row `zrow`.
+void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
+                           double c0, double* pred, double* err);
+void ck_launch_mfma_probe(hipStream_t s, int32_t* out);

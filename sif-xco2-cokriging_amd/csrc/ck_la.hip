@@ -1,0 +1,355 @@
+// ck_la.hip -- dense FP64 linear algebra kernels for gfx950 (MI355X).
+//
+//   k_gemm_nt    C -= A B^T on v_mfma_f64_16x16x4_f64, LDS-tiled, register-prefetched.
+//                This is the trailing update of the blocked Cholesky (cho_factor,
+//                src/joint_prediction.py:69) and of the forward substitution
+//                (first half of cho_solve, src/joint_prediction.py:68-73): the one
+//                genuinely dense contraction on the path.
+//   k_potrf64    Cholesky of a 64 x 64 diagonal block in LDS (one workgroup).
+//   k_trsm64     X L^T = A for 64-column row slabs, one row per lane.
+//   k_reduce_pred  fused prediction / variance reductions (src/joint_prediction.py:74-78
+//                without the m x m matrix).
+//
+// All matrices are row-major.  Dimensions handed to these kernels are padded
+// by the host (ck_api.hip) so that no edge predication is needed in the hot loops.
+#include "ck_internal.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------
+// MFMA GEMM:  C (M x N) -= A (M x K) * B (N x K)^T
+// ---------------------------------------------------------------------------------------
+// Workgroup tile 256 x BN (BN = 128 or 64), K step 16, 512 threads = 8 waves laid out
+// 4 (M) x 2 (N); each wave owns 64 x (BN/2) = 4 x WN MFMA tiles of 16 x 16, i.e. 16 or 8
+// independent accumulators (the f64 MFMA is 64 cycles deep on the SIMD, so one wave's
+// own accumulators already cover its dependent-issue latency).
+//
+// v_mfma_f64_16x16x4_f64 operand map (cdna_hip_programming.md section 3, probed by
+// ck_debug_mfma_probe):  lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+//
+// LDS rows hold 16 doubles of K plus 2 doubles of padding (144 B): for ds_read_b64 the 32
+// lanes of a half-wave (16 rows x 2 k) then hit 64 distinct banks.
+#define GEMM_LDK 18
+#define GEMM_BK 16
+
+template <int WN>
+__device__ __forceinline__ void gemm_tile(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
+                                          const double* __restrict__ B, long ldb, long r0, long c0, int K,
+                                          double* lds) {
+    constexpr int BN = WN * 32;
+    constexpr int BCH = BN * 8 / 512;  // 16-byte chunks of the B tile per thread (2 or 1)
+    constexpr int STAGE = (CK_BM + BN) * GEMM_LDK;   // doubles per LDS stage: A tile then B tile
+    constexpr int BOFF = CK_BM * GEMM_LDK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 15, kq = lane >> 4;
+
+    // global -> register staging assignments (one 16-byte chunk = 2 doubles of K)
+    const double* a_src[4];
+    int a_dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
+        a_src[u] = A + (r0 + row) * lda + ch * 2;
+        a_dst[u] = row * GEMM_LDK + ch * 2;
+    }
+    const double* b_src[BCH];
+    int b_dst[BCH];
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
+        b_src[u] = B + (c0 + row) * ldb + ch * 2;
+        b_dst[u] = row * GEMM_LDK + ch * 2;
+    }
+
+    d4_t acc[4][WN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    d2_t ra[4], rb[BCH];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u]);
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(lds + a_dst[u]) = ra[u];
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(lds + BOFF + b_dst[u]) = rb[u];
+    __syncthreads();
+
+    const int nst = K / GEMM_BK;
+    const int a_rd = (wm * 64 + li) * GEMM_LDK + kq;
+    const int b_rd = (wn * (WN * 16) + li) * GEMM_LDK + kq;
+
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1 < nst);
+        if (more) {
+            const int k0 = (st + 1) * GEMM_BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u] + k0);
+#pragma unroll
+            for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u] + k0);
+        }
+        const double* as = lds + cur * STAGE + a_rd;
+        const double* bs = lds + cur * STAGE + BOFF + b_rd;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[WN];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = as[i * 16 * GEMM_LDK + kk * 4];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = bs[j * 16 * GEMM_LDK + kk * 4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            double* nx = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(nx + a_dst[u]) = ra[u];
+#pragma unroll
+            for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(nx + BOFF + b_dst[u]) = rb[u];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C -= acc.  Register r of lane l is D[(l >> 4) + 4 r][l & 15].
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const long col = c0 + wn * (WN * 16) + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + wm * 64 + i * 16 + kq + 4 * r;
+                double* p = C + row * ldc + col;
+                *p = *p - acc[i][j][r];
+            }
+        }
+    }
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b and b + 8 share an XCD (and its L2);
+// give each XCD a contiguous run of tiles so that neighbouring tiles (same A rows) meet in one L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int xcd = b & 7, qq = nblk >> 3, rr = nblk & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+}
+
+// plain (optionally batched over blockIdx.y) form
+template <int WN>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long ldc, const double* __restrict__ A,
+                                                     long lda, const double* __restrict__ B, long ldb, int tiles_m,
+                                                     int tiles_n, int K, int lower, long diag_off, long sC, long sA,
+                                                     long sB) {
+    constexpr int BN = WN * 32;
+    __shared__ double lds[2 * (CK_BM + BN) * GEMM_LDK];
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * CK_BM, c0 = (long)tn * BN;
+    if (lower && r0 + (CK_BM - 1) + diag_off < c0) return;
+    const long y = blockIdx.y;
+    gemm_tile<WN>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
+}
+
+// Trailing update of the Cholesky for ALL locally owned block columns J > K in one launch:
+//   sig[J] (rows J*NB.., NB cols) -= P[(J-K)*NB.., :] * P[(J-K)*NB .. (J-K+1)*NB, :]^T
+// where P is the factored panel K (rows K*NB.. of L, NB columns, ld = NB).
+// blockIdx.y enumerates the owned J = J0 + y * Jstep; blockIdx.x the tiles of the largest one.
+__global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restrict__ sigptr,
+                                                         const double* __restrict__ P, int K, int J0, int Jstep,
+                                                         long Npad) {
+    __shared__ double lds[2 * (CK_BM + 128) * GEMM_LDK];
+    const int J = J0 + (int)blockIdx.y * Jstep;
+    const long M = Npad - (long)J * CK_NB;
+    const int tiles_m = (int)(M / CK_BM), tiles_n = CK_NB / 128;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * CK_BM, c0 = (long)tn * 128;
+    if (r0 + (CK_BM - 1) < c0) return;
+    const double* A = P + (long)(J - K) * CK_NB * CK_NB;
+    gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
+}
+
+void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
+                       int64_t sC, int64_t sA, int64_t sB) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
+    const int tiles_m = (int)(M / CK_BM);
+    if (N % 128 == 0) {
+        const int tiles_n = (int)(N / 128);
+        k_gemm_nt<4><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n,
+                                                                            (int)K, lower, diag_off, sC, sA, sB);
+    } else {
+        const int tiles_n = (int)(N / 64);
+        k_gemm_nt<2><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n,
+                                                                            (int)K, lower, diag_off, sC, sA, sB);
+    }
+}
+
+void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
+                           int nJ, int64_t Npad) {
+    if (nJ <= 0) return;
+    const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
+    const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
+    k_syrk_panels<<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
+}
+
+// ---------------------------------------------------------------------------------------
+// 64 x 64 Cholesky of a diagonal block (one workgroup, LDS resident)
+// ---------------------------------------------------------------------------------------
+// Right-looking on the UNSCALED columns: at step j every element (i, k), j < k <= i, gets
+// a[i][k] -= a[i][j] a[k][j] / a[j][j]; the pivots a[j][j] are final after step j - 1, so the
+// scaling L[i][j] = a[i][j] / sqrt(a[j][j]) is applied once at the end.  One barrier per step.
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info) {
+    __shared__ double a[64][65];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        a[r][c] = A[r * ld + c];
+    }
+    __syncthreads();
+    const int i = tid >> 2, kb = (tid & 3) * 16;
+    bool failed = false;
+    for (int j = 0; j < 63; ++j) {
+        const double piv = a[j][j];
+        if (tid == 0 && !failed && !(piv > 0.0)) {
+            failed = true;
+            atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + j + 1));
+        }
+        if (i > j) {
+            const double f = a[i][j] * (1.0 / piv);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = kb + kk;
+                if (k > j && k <= i) a[i][k] -= f * a[k][j];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && !failed && !(a[63][63] > 0.0))
+        atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + 64));
+    // scale and write back the lower triangle
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        if (c <= r) {
+            const double d = sqrt(a[c][c]);
+            A[r * ld + c] = (c == r) ? d : a[r][c] / d;
+        }
+    }
+}
+
+void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev) {
+    k_potrf64<<<dim3(1), dim3(256), 0, s>>>(A, ld, global_index0, info_dev);
+}
+
+// ---------------------------------------------------------------------------------------
+// X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
+                                                long ldl) {
+    __shared__ double Ls[64][65];
+    __shared__ double T[64][65];
+    const int lane = threadIdx.x;
+    double* base = A + (long)blockIdx.x * 64 * ld;
+    for (int idx = lane; idx < 64 * 64; idx += 64) {
+        const int r = idx >> 6, c = idx & 63;
+        Ls[r][c] = L[r * ldl + c];
+        T[r][c] = base[r * ld + c];
+    }
+    __syncthreads();
+    double x[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) x[c] = T[lane][c];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        x[c] = x[c] / Ls[c][c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) T[lane][c] = x[c];
+    __syncthreads();
+    for (int idx = lane; idx < 64 * 64; idx += 64) {
+        const int r = idx >> 6, c = idx & 63;
+        base[r * ld + c] = T[r][c];
+    }
+}
+
+void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl) {
+    if (nrows <= 0) return;
+    k_trsm64<<<dim3((unsigned)(nrows / 64)), dim3(64), 0, s>>>(A, ld, L, ldl);
+}
+
+// ---------------------------------------------------------------------------------------
+// pred / pred_err reductions over the solved right-hand-side rows
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_pred(const double* __restrict__ aux, long mpad, int n_panels,
+                                                      long m, long zrow, double c0, double* __restrict__ pred,
+                                                      double* __restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int K = 0; K < n_panels; ++K) {
+        const double* pb = aux + (long)K * mpad * CK_NB;
+        const double* xr = pb + row * CK_NB;
+        const double* yr = pb + zrow * CK_NB;
+#pragma unroll
+        for (int t = 0; t < CK_NB; t += 128) {
+            const d2_t x = *reinterpret_cast<const d2_t*>(xr + t + lane * 2);
+            const d2_t y = *reinterpret_cast<const d2_t*>(yr + t + lane * 2);
+            s1 += x[0] * y[0] + x[1] * y[1];
+            s2 += x[0] * x[0] + x[1] * x[1];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    if (lane == 0) {
+        pred[row] = s1;
+        double e = sqrt(c0 - s2);   // negative variance -> NaN -> 0.0 (np.nan_to_num, joint_prediction.py:78)
+        err[row] = (e == e) ? e : 0.0;
+    }
+}
+
+void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
+                           double c0, double* pred, double* err) {
+    if (m <= 0) return;
+    k_reduce_pred<<<dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s>>>(aux, mpad, n_panels, m, zrow, c0, pred, err);
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA operand / result map probe (diagnostic)
+// ---------------------------------------------------------------------------------------
+__global__ void k_mfma_probe(int32_t* out) {
+    const int l = threadIdx.x;
+    const int i = l & 15, k = l >> 4;
+    d4_t z = {0, 0, 0, 0};
+    // run 1: D[i][j] = i + 1        (A[i][0] = i + 1, B[0][j] = 1)
+    d4_t d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(k == 0 ? (double)(i + 1) : 0.0, k == 0 ? 1.0 : 0.0, z, 0, 0, 0);
+    // run 2: D[i][j] = j + 1
+    d4_t d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(k == 0 ? 1.0 : 0.0, k == 0 ? (double)(i + 1) : 0.0, z, 0, 0, 0);
+    // run 3: both operands non-zero only at k == 2 -> 7 everywhere iff the k maps agree
+    d4_t d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(k == 2 ? 1.0 : 0.0, k == 2 ? 7.0 : 0.0, z, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) {
+        out[(l * 4 + r) * 3 + 0] = (int)d1[r] - 1;
+        out[(l * 4 + r) * 3 + 1] = (int)d2[r] - 1;
+        out[(l * 4 + r) * 3 + 2] = (int)d3[r];
+    }
+}
+
+void ck_launch_mfma_probe(hipStream_t s, int32_t* out) { k_mfma_probe<<<dim3(1), dim3(64), 0, s>>>(out); }

@@ -1,0 +1,221 @@
+"""Global ("joint") cokriging -- same call signatures as the reference's
+``joint_prediction`` module (src/joint_prediction.py), numeric core in HIP.
+
+    from sif_xco2_cokriging_amd import joint_prediction as prediction
+    cokrig = prediction.Predictor(mod, mf, fast_dist=False, dist_units=None)
+    ds = cokrig(1, pcoords, postprocess=False)
+
+``mod`` / ``mf`` may be this package's ``model.MultivariateMatern`` / ``fields.MultiField``
+or the reference's own objects: only ``mod.n_procs``, ``mod.params.<p>.values``,
+``mf.n_procs`` and ``mf.fields[k].coords_main / values_main / timestamp / ds.attrs``
+are read.
+
+What runs on the GPU (include/cokrige.h): assembly of Sigma and c0, blocked FP64-MFMA
+Cholesky, forward substitution fused with the prediction / variance reductions.  The
+factor is kept on the device, so further calls with new ``pcoords`` or another ``i`` cost
+one substitution sweep each.
+
+Deviations from the reference, all outside the arithmetic:
+  * the reference's ``_verify_model`` factorises the (m+N)x(m+N) stacked matrix only to
+    emit a warning (src/joint_prediction.py:60-66,260-274).  Here the same warning is
+    raised from the quantity that decides it in practice: a non-positive prediction
+    variance (see ``_warn_if_invalid``).
+  * without xarray installed the result is a pandas DataFrame indexed by the coordinate
+    columns instead of an ``xarray.Dataset`` (same columns ``pred``, ``pred_err``).
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pandas as pd
+from numpy.linalg import LinAlgError
+
+from . import native
+from .fields import metric_of
+from .model import configure_handle
+
+try:  # the reference returns xarray objects; keep that when xarray exists
+    import xarray as xr
+except Exception:  # pragma: no cover - absent in the build image
+    xr = None
+
+
+class Predictor:
+    """Multivariate prediction framework (src/joint_prediction.py:13-33)."""
+
+    def __init__(self, mod, mf, covariates=None, dist_units: str = "km", fast_dist: bool = True,
+                 device: int = 0) -> None:
+        if mod.n_procs != mf.n_procs:
+            raise ValueError("Number of theoretical processes different from empirical processes.")
+        self.n_procs = mod.n_procs
+        self.mod = mod
+        self.mf = mf
+        self.covariates = covariates
+        self.dist_units = dist_units
+        self.fast_dist = fast_dist
+        self.device = device
+        self.timings = {}
+        self._h = None
+
+    # -- device state -------------------------------------------------------------------------
+    def _new_handle(self, drop=None):
+        """Handle with model, metric and data loaded; ``drop=(i, ix)`` withholds datum ix of
+        process i (LOOCV, src/joint_prediction.py:56-58,112-113,140-146)."""
+        h = native.Handle(self.device)
+        configure_handle(h, self.mod)
+        h.set_metric(metric_of(self.dist_units, self.fast_dist))
+        for k in range(self.n_procs):
+            c = np.asarray(self.mf.fields[k].coords_main, dtype=np.float64)
+            v = np.asarray(self.mf.fields[k].values_main, dtype=np.float64)
+            if drop is not None and drop[0] == k:
+                c = np.delete(c, drop[1], axis=0)
+                v = np.delete(v, drop[1], axis=0)
+            h.set_data(k, c, v)
+        return h
+
+    @staticmethod
+    def _factor(h):
+        h.assemble_joint()
+        info = h.factor()
+        if info != 0:
+            # scipy.linalg.cho_factor's message (raised uncaught at src/joint_prediction.py:69)
+            raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
+
+    def _factored_handle(self):
+        if self._h is None:
+            h = self._new_handle()
+            self._factor(h)
+            self._h = h
+        return self._h
+
+    def predict_arrays(self, i: int, pcoords, cv_ix: int = None):
+        """(pred, pred_err) as arrays -- the numeric body of ``__call__``
+        (src/joint_prediction.py:49-78)."""
+        pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
+        if cv_ix is None:
+            h = self._factored_handle()
+            pred, err = h.predict(i, pc)
+            self.timings = h.timings()
+        else:
+            h = self._new_handle(drop=(i, cv_ix))
+            try:
+                self._factor(h)
+                pred, err = h.predict(i, pc)
+            finally:
+                h.close()
+        return pred, err
+
+    def _warn_if_invalid(self, pred_err):
+        # The stacked matrix of _verify_model is positive definite iff Sigma is (else we have
+        # already raised) and the prediction covariance Schur complement is; a prediction
+        # variance <= 0 (printed as pred_err == 0) is how that fails at data locations.
+        if np.any(pred_err <= 0.0):
+            warnings.warn("Prediction joint covariance matrix is not positive definte; model"
+                          " technically invalid.")
+
+    # -- reference call signature ----------------------------------------------------------------
+    def __call__(self, i: int, pcoords: pd.DataFrame, postprocess: bool = True, cv_ix: int = None):
+        """Prediction and standard error of process ``i`` at ``pcoords`` (format [[lat, lon]])
+        (src/joint_prediction.py:35-92)."""
+        self.i = i
+        if cv_ix is not None:
+            p = np.asarray(pcoords, dtype=np.float64).ravel()
+            pcoords = pd.DataFrame({"d1": p[0], "d2": p[1]}, index=[0])
+        elif not isinstance(pcoords, pd.DataFrame):
+            a = np.atleast_2d(np.asarray(pcoords, dtype=np.float64))
+            pcoords = pd.DataFrame({"d1": a[:, 0], "d2": a[:, 1]})
+        pred, err = self.predict_arrays(i, pcoords.values[:, :2], cv_ix=cv_ix)
+        if cv_ix is None:
+            self._warn_if_invalid(err)
+        df_pred = pcoords.copy()
+        df_pred["pred"] = pred
+        df_pred["pred_err"] = err
+        if postprocess:
+            df_pred = df_pred.rename(columns={"d1": "lat", "d2": "lon"})
+            return self._postprocess_predictions(df_pred)
+        out = df_pred.set_index(pcoords.columns.values.tolist())
+        if xr is None:
+            return out
+        ds = out.to_xarray()
+        ts = self.mf.fields[self.i].timestamp
+        try:
+            np.isnan(ts)
+            return ds
+        except TypeError:
+            return ds.assign_coords(coords={"time": np.datetime64(ts)})
+
+    def _postprocess_predictions(self, df: pd.DataFrame):
+        """Back to the scale of the original data: undo the standardisation, add the OLS
+        spatial trend and the temporal trend (src/joint_prediction.py:155-205).  O(m) host
+        work on the attributes src/fields.py:345-375 stored."""
+        at = self.mf.fields[self.i].ds.attrs
+        out = df[["lon", "lat"]].copy()
+        out["pred"] = df["pred"].values * at["scale_fact"] + at["spatial_mean"]
+        out["pred_err"] = df["pred_err"].values * at["scale_fact"]
+        if self.covariates is None:
+            cov = df[["lon", "lat"]].copy()
+            keep = np.ones(len(df), dtype=bool)
+        else:
+            if xr is None:
+                raise RuntimeError("covariates are xarray objects in the reference; xarray is not installed")
+            sel = self.covariates.sel(time=self.mf.fields[self.i].timestamp)
+            vals = sel.to_dataframe(name="covariates").reset_index()
+            merged = df[["lon", "lat"]].merge(vals[["lon", "lat", "covariates"]], on=["lon", "lat"], how="left")
+            keep = merged["covariates"].notna().values
+            cov = merged.loc[keep, ["covariates"]].copy()
+        for k, name in enumerate(cov.columns):
+            cov[name] = (cov[name] - at["covariate_means"][k]) / at["covariate_scales"][k]
+        trend = np.full(len(df), np.nan)
+        trend[keep] = at["spatial_model"].predict(cov)
+        out["pred"] = out["pred"] + trend + at["temporal_trend"]
+        out = out.set_index(["lon", "lat"])
+        if xr is None:
+            return out
+        ds = out.to_xarray()
+        return ds.assign_coords(coords={"time": np.datetime64(self.mf.fields[self.i].timestamp)})
+
+    def cross_validation(self, i: int, postprocess: bool = True) -> pd.DataFrame:
+        """Leave-one-out cross-validation at each data location of process ``i``
+        (src/joint_prediction.py:207-257): datum withheld, everything re-solved."""
+        names = ["lat", "lon"] if postprocess else ["d1", "d2"]
+        f = self.mf.fields[i]
+        data = pd.DataFrame(np.hstack((f.coords_main, np.atleast_2d(f.values_main).T)), columns=names + ["data"])
+        pred = np.empty(len(data))
+        err = np.empty(len(data))
+        for ix in range(len(data)):
+            p, e = self.predict_arrays(i, f.coords_main[ix], cv_ix=ix)
+            pred[ix], err[ix] = p[0], e[0]
+        if postprocess:
+            at = f.ds.attrs
+            tmp = pd.DataFrame({"lat": data["lat"], "lon": data["lon"], "pred": pred, "pred_err": err})
+            self.i = i
+            pp = self._postprocess_predictions(tmp)
+            pp = pp.to_dataframe().reset_index() if xr is not None and not isinstance(pp, pd.DataFrame) else pp.reset_index()
+            data = data.merge(pp.dropna(subset=["pred"]), on=names, how="outer")
+        else:
+            data["pred"], data["pred_err"] = pred, err
+        data["residual"] = data["data"] - data["pred"]
+        return data[names + ["data", "pred", "residual", "pred_err"]]
+
+
+def prediction_coords(extents: tuple = (-125, -65, 22, 58), lon_res: float = 0.5, lat_res: float = 0.5,
+                      land_only: bool = True) -> pd.DataFrame:
+    """Prediction grid [lat, lon] (src/joint_prediction.py:277-283).  The reference keeps land
+    cells only, through regionmask's Natural Earth polygons; where regionmask is not
+    installed ask for the full rectangle with ``land_only=False``."""
+    lon = np.arange(extents[0], extents[1] + 0.5 * lon_res, lon_res)
+    lat = np.arange(extents[2], extents[3] + 0.5 * lat_res, lat_res)
+    if land_only:
+        try:
+            import regionmask  # noqa: F401
+        except Exception as e:
+            raise RuntimeError("land masking needs regionmask (as in the reference); "
+                               "use land_only=False for the full rectangle") from e
+        land = regionmask.defined_regions.natural_earth_v5_0_0.land_110
+        mask = land.mask(lon, lat)
+        la, lo = np.meshgrid(lat, lon, indexing="ij")
+        ok = ~np.isnan(np.asarray(mask))
+        return pd.DataFrame({"lat": la[ok], "lon": lo[ok]})
+    la, lo = np.meshgrid(lat, lon, indexing="ij")
+    return pd.DataFrame({"lat": la.ravel(), "lon": lo.ravel()})

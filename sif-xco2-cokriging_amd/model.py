@@ -1,0 +1,177 @@
+"""Host-side mirror of the covariance part of the reference's ``model`` module
+(src/model.py): parameter containers and ``MultivariateMatern`` with the same
+attribute and method names the notebooks use.  The numbers come from the HIP
+library (``ck_cov_lags``): distance -> Matern auto/cross-covariance with a
+device K_nu; nothing is evaluated in numpy/scipy here.
+
+Not mirrored (out of the hot path): ``fit`` and
+``FittedVariogram``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from . import native
+
+
+class _Param:
+    """An n_procs x n_procs parameter array, NaN where the parameter does not exist
+    (cf. MarginalParam / CrossParam / RhoParam, src/model.py:16-106)."""
+
+    def __init__(self, name, default, bounds, n_procs, where):
+        self.name, self.default, self.bounds, self.n_procs = name, default, bounds, n_procs
+        self._where = where  # "diag" | "triu" | "striu"
+        self.values = np.full((n_procs, n_procs), np.nan)
+        self.reset_values()
+
+    def _index(self):
+        if self._where == "diag":
+            return np.diag_indices(self.n_procs)
+        return np.triu_indices(self.n_procs, k=0 if self._where == "triu" else 1)
+
+    def get_names(self):
+        r, c = self._index()
+        return [f"{self.name}_{i + 1}{j + 1}" for i, j in zip(r, c)]
+
+    def get_values(self):
+        return self.values[self._index()]
+
+    def set_values(self, x):
+        self.values[self._index()] = x
+        return self
+
+    def reset_values(self):
+        self.values[self._index()] = self.default
+        return self
+
+    def count_params(self):
+        return len(self._index()[0])
+
+    def to_dataframe(self):
+        return pd.DataFrame({"name": self.get_names(), "value": self.get_values(),
+                             "bounds": [self.bounds] * self.count_params()})
+
+
+class MaternParams:
+    """sigma, nu, len_scale, nugget, rho with the reference's defaults, bounds and flat
+    order sigma_11 sigma_22 nu_11 nu_12 nu_22 len_11 len_12 len_22 nugget_11 nugget_22 rho_12
+    (src/model.py:109-169)."""
+
+    def __init__(self, n_procs: int = 2) -> None:
+        self.n_procs = n_procs
+        self.sigma = _Param("sigma", 1.0, (0.4, 3.5), n_procs, "diag")
+        self.nu = _Param("nu", 1.5, (0.2, 3.5), n_procs, "triu")
+        self.len_scale = _Param("len_scale", 5e2, (1e2, 2e3), n_procs, "triu")
+        self.nugget = _Param("nugget", 0.0, (0.0, 0.2), n_procs, "diag")
+        self.rho = _Param("rho", np.nan if n_procs == 1 else 0.0, (-1.0, 1.0), n_procs, "striu")
+        self._params = [self.sigma, self.nu, self.len_scale, self.nugget, self.rho]
+        self.n_params = sum(p.count_params() for p in self._params)
+
+    def to_dataframe(self):
+        return pd.concat([p.to_dataframe() for p in self._params], ignore_index=True)
+
+    def get_names(self):
+        return self.to_dataframe()["name"].values
+
+    def get_values(self):
+        return self.to_dataframe()["value"].values
+
+    def get_bounds(self):
+        return self.to_dataframe()["bounds"].values
+
+    def set_values(self, x):
+        x = np.asarray(x, dtype=float)
+        if len(x) != self.n_params:
+            raise ValueError("Incorrect number of parameters in input array.")
+        at = 0
+        for p in self._params:
+            k = p.count_params()
+            p.set_values(x[at:at + k])
+            at += k
+        return self
+
+    def reset_values(self):
+        for p in self._params:
+            p.reset_values()
+        return self
+
+    def set_bounds(self, **kwargs):
+        for name, bounds in kwargs.items():
+            if name not in ("sigma", "nu", "len_scale", "nugget", "rho"):
+                raise AttributeError(f"`{name}` is not a valid parameter.")
+            getattr(self, name).bounds = bounds
+        return self
+
+
+def model_arrays(mod):
+    """(n_procs, sigma, nu3, len3, nugget, rho12) from any object with the reference's
+    ``mod.params.<name>.values`` layout (ours or the reference's own MultivariateMatern)."""
+    p = mod.params
+    n = int(mod.n_procs)
+    sig = np.diag(np.asarray(p.sigma.values, dtype=float)).copy()
+    nug = np.diag(np.asarray(p.nugget.values, dtype=float)).copy()
+    nu = np.asarray(p.nu.values, dtype=float)
+    ls = np.asarray(p.len_scale.values, dtype=float)
+    if n == 1:
+        return 1, sig, np.array([nu[0, 0]] * 3), np.array([ls[0, 0]] * 3), nug, 0.0
+    if n != 2:
+        raise ValueError("the HIP path supports n_procs = 1 or 2")
+    rho = float(np.asarray(p.rho.values, dtype=float)[0, 1])
+    return 2, sig, np.array([nu[0, 0], nu[0, 1], nu[1, 1]]), np.array([ls[0, 0], ls[0, 1], ls[1, 1]]), nug, rho
+
+
+def configure_handle(h: "native.Handle", mod):
+    n, sig, nu, ls, nug, rho = model_arrays(mod)
+    h.set_model(n, sig, nu, ls, nug, rho)
+
+
+class MultivariateMatern:
+    """Multivariate Matern covariance model (Gneiting et al., 2010) -- same public
+    surface as src/model.py:172-222 for the covariance functions."""
+
+    def __init__(self, n_procs: int = 2, params: MaternParams = None, device: int = 0) -> None:
+        self.n_procs = n_procs
+        self.params = MaternParams(n_procs=n_procs) if params is None else params
+        self.fit_result = None
+        self._device = device
+        self._h = None
+
+    def _handle(self):
+        if self._h is None:
+            self._h = native.Handle(self._device)
+        configure_handle(self._h, self)   # parameters may have been edited in place
+        return self._h
+
+    def _eval(self, i, j, h, use_nugget):
+        h = np.atleast_1d(np.asarray(h, dtype=np.float64))
+        return self._handle().cov_lags(i, j, h, use_nugget=use_nugget)
+
+    def covariance(self, i: int, h, use_nugget: bool = True) -> np.ndarray:
+        """sigma_i^2 rho_ii(h) + nugget_i [h == 0]   (src/model.py:193-197)."""
+        return self._eval(i, i, h, use_nugget)
+
+    def cross_covariance(self, i: int, j: int, h) -> np.ndarray:
+        """rho_ij prod(sigma) rho^Matern_ij(h)   (src/model.py:199-207)."""
+        if i > j:
+            i, j = j, i
+        return self._eval(i, j, h, False)
+
+    def correlation(self, i: int, j: int, h) -> np.ndarray:
+        """src/model.py:188-191."""
+        if i > j:
+            i, j = j, i
+        if i == j:
+            return self._eval(i, i, h, False) / self.params.sigma.values[i, i] ** 2
+        amp = self.params.rho.values[i, j] * np.nanprod(self.params.sigma.values)
+        return self._eval(i, j, h, False) / amp
+
+    def semivariance(self, i: int, h) -> np.ndarray:
+        """src/model.py:209-213."""
+        s2 = self.params.sigma.values[i, i] ** 2
+        return s2 - self._eval(i, i, h, False) + self.params.nugget.values[i, i]
+
+    def cross_semivariance(self, i: int, j: int, h) -> np.ndarray:
+        """src/model.py:215-222."""
+        sill = 0.5 * np.nansum(self.params.sigma.values ** 2 + self.params.nugget.values)
+        return sill - self.cross_covariance(i, j, h)

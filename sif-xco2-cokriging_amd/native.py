@@ -1,0 +1,254 @@
+"""ctypes binding of libcokrige_hip.so (C ABI: include/cokrige.h).
+
+The library is built in-tree by ``build_native.py`` (hipcc, gfx950).  Loading fails
+loudly when it is missing -- there is deliberately no numpy fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcokrige_hip.so")
+
+METRIC_HAVERSINE = 0
+METRIC_EUCLID = 1
+APPLY_SIGMA = 1
+APPLY_AUX = 2
+
+_dp = POINTER(c_double)
+_lib = None
+
+# name -> argtypes (every function returns int except ck_last_error)
+_PROTOS = {
+    "ck_version": [],
+    "ck_device_count": [POINTER(c_int)],
+    "ck_create": [c_int, POINTER(c_void_p)],
+    "ck_destroy": [c_void_p],
+    "ck_set_stream": [c_void_p, c_void_p],
+    "ck_set_arena": [c_void_p, c_void_p, c_int64],
+    "ck_synchronize": [c_void_p],
+    "ck_set_model": [c_void_p, c_int, _dp, _dp, _dp, _dp, c_double],
+    "ck_set_metric": [c_void_p, c_int],
+    "ck_set_partition": [c_void_p, c_int, c_int],
+    "ck_set_data": [c_void_p, c_int, _dp, _dp, c_int64],
+    "ck_distance_dense": [c_void_p, _dp, c_int64, _dp, c_int64, _dp],
+    "ck_cov_dense": [c_void_p, c_int, c_int, _dp, c_int64, _dp, c_int64, c_int, _dp],
+    "ck_cov_lags": [c_void_p, c_int, c_int, _dp, c_int64, c_int, _dp],
+    "ck_assemble_joint": [c_void_p],
+    "ck_factor": [c_void_p, POINTER(c_int64)],
+    "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
+    "ck_num_panels": [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
+    "ck_panel_owner": [c_void_p, c_int, POINTER(c_int)],
+    "ck_aux_begin": [c_void_p, c_int, _dp, c_int64],
+    "ck_panel_factor": [c_void_p, c_int],
+    "ck_panel_buffer": [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)],
+    "ck_panel_apply": [c_void_p, c_int, c_int],
+    "ck_aux_finish": [c_void_p, _dp, _dp],
+    "ck_factor_info": [c_void_p, POINTER(c_int64)],
+    "ck_debug_get_lower": [c_void_p, _dp, c_int64],
+    "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
+    "ck_set_option": [c_void_p, c_char_p, c_int64],
+    "ck_timings": [c_void_p, _dp, c_int],
+    "ck_dev_gemm_nt": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                       c_int],
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def exported_names():
+    """Every symbol include/cokrige.h declares (used by the symbol-export test)."""
+    return ["ck_last_error"] + list(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python sif-xco2-cokriging_amd/build_native.py` "
+                "(hipcc, gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.ck_last_error.restype = c_char_p
+        L.ck_last_error.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = c_int
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise NativeError(lib().ck_last_error().decode("utf-8", "replace"))
+
+
+def _f64(a, shape2=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape2 is not None:
+        a = a.reshape(-1, shape2)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count() -> int:
+    n = c_int(0)
+    _chk(lib().ck_device_count(byref(n)))
+    return n.value
+
+
+class Handle:
+    """One GPU, one HIP stream, one cokriging problem (see include/cokrige.h)."""
+
+    def __init__(self, device: int = 0):
+        self._h = c_void_p()
+        self._keep = []
+        _chk(lib().ck_create(int(device), byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ck_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        _chk(lib().ck_set_stream(self._h, c_void_p(stream_ptr or 0)))
+
+    def set_arena(self, dev_ptr: int, nbytes: int, keepalive=None):
+        self._keep.append(keepalive)
+        _chk(lib().ck_set_arena(self._h, c_void_p(dev_ptr), int(nbytes)))
+
+    def synchronize(self):
+        _chk(lib().ck_synchronize(self._h))
+
+    def set_option(self, name: str, value: int):
+        _chk(lib().ck_set_option(self._h, name.encode(), int(value)))
+
+    def set_model(self, n_procs, sigma, nu, len_scale, nugget, rho12=0.0):
+        s, v, l, g = (_f64(x).ravel() for x in (sigma, nu, len_scale, nugget))
+        if n_procs == 2 and (s.size != 2 or v.size != 3 or l.size != 3 or g.size != 2):
+            raise ValueError("bivariate model needs sigma[2], nu[3], len_scale[3], nugget[2]")
+        _chk(lib().ck_set_model(self._h, int(n_procs), _p(s), _p(v), _p(l), _p(g), float(rho12)))
+
+    def set_metric(self, metric: int):
+        _chk(lib().ck_set_metric(self._h, int(metric)))
+
+    def set_partition(self, rank: int, world: int):
+        _chk(lib().ck_set_partition(self._h, int(rank), int(world)))
+
+    def set_data(self, k: int, coords, values):
+        c = _f64(coords, 2)
+        v = _f64(values).ravel()
+        if c.shape[0] != v.size:
+            raise ValueError("coords and values disagree in length")
+        _chk(lib().ck_set_data(self._h, int(k), _p(c), _p(v), c.shape[0]))
+
+    # -- element-wise surface -------------------------------------------------------------
+    def distance_dense(self, A, B):
+        A, B = _f64(A, 2), _f64(B, 2)
+        out = np.empty((A.shape[0], B.shape[0]))
+        _chk(lib().ck_distance_dense(self._h, _p(A), A.shape[0], _p(B), B.shape[0], _p(out)))
+        return out
+
+    def cov_dense(self, i, j, A, B, use_nugget=True):
+        A, B = _f64(A, 2), _f64(B, 2)
+        out = np.empty((A.shape[0], B.shape[0]))
+        _chk(lib().ck_cov_dense(self._h, int(i), int(j), _p(A), A.shape[0], _p(B), B.shape[0], int(bool(use_nugget)),
+                                _p(out)))
+        return out
+
+    def cov_lags(self, i, j, h, use_nugget=True):
+        h = _f64(h)
+        out = np.empty(h.shape)
+        _chk(lib().ck_cov_lags(self._h, int(i), int(j), _p(h.ravel()), h.size, int(bool(use_nugget)), _p(out)))
+        return out
+
+    # -- joint path -------------------------------------------------------------------------
+    def assemble_joint(self):
+        _chk(lib().ck_assemble_joint(self._h))
+
+    def factor(self) -> int:
+        info = c_int64(0)
+        _chk(lib().ck_factor(self._h, byref(info)))
+        return info.value
+
+    def predict(self, i, pcoords):
+        pc = _f64(pcoords, 2)
+        m = pc.shape[0]
+        pred, err = np.empty(m), np.empty(m)
+        _chk(lib().ck_predict(self._h, int(i), _p(pc), m, _p(pred), _p(err)))
+        return pred, err
+
+    # -- step-wise form -----------------------------------------------------------------------
+    def num_panels(self):
+        n, w, npad = c_int(0), c_int(0), c_int64(0)
+        _chk(lib().ck_num_panels(self._h, byref(n), byref(w), byref(npad)))
+        return n.value, w.value, npad.value
+
+    def panel_owner(self, K):
+        o = c_int(0)
+        _chk(lib().ck_panel_owner(self._h, int(K), byref(o)))
+        return o.value
+
+    def aux_begin(self, i, pcoords):
+        pc = _f64(pcoords, 2)
+        self._m = pc.shape[0]
+        _chk(lib().ck_aux_begin(self._h, int(i), _p(pc), pc.shape[0]))
+
+    def panel_factor(self, K):
+        _chk(lib().ck_panel_factor(self._h, int(K)))
+
+    def panel_buffer(self, K):
+        p, nb = c_void_p(), c_int64(0)
+        _chk(lib().ck_panel_buffer(self._h, int(K), byref(p), byref(nb)))
+        return p.value, nb.value
+
+    def panel_apply(self, K, what):
+        _chk(lib().ck_panel_apply(self._h, int(K), int(what)))
+
+    def aux_finish(self):
+        pred, err = np.empty(self._m), np.empty(self._m)
+        _chk(lib().ck_aux_finish(self._h, _p(pred), _p(err)))
+        return pred, err
+
+    def factor_info(self) -> int:
+        info = c_int64(0)
+        _chk(lib().ck_factor_info(self._h, byref(info)))
+        return info.value
+
+    # -- diagnostics -----------------------------------------------------------------------------
+    def debug_get_lower(self, n):
+        out = np.empty((n, n))
+        _chk(lib().ck_debug_get_lower(self._h, _p(out), int(n)))
+        return out
+
+    def mfma_probe(self):
+        out = np.empty(64 * 4 * 3, dtype=np.int32)
+        _chk(lib().ck_debug_mfma_probe(self._h, out.ctypes.data_as(POINTER(c_int32))))
+        return out.reshape(64, 4, 3)
+
+    def timings(self):
+        out = np.zeros(8)
+        _chk(lib().ck_timings(self._h, _p(out), 8))
+        keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "gemm_ms", "gemm_launches"]
+        return dict(zip(keys, out.tolist()))
+
+    def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):
+        _chk(lib().ck_dev_gemm_nt(self._h, c_void_p(C_ptr), ldc, c_void_p(A_ptr), lda, c_void_p(B_ptr), ldb, M, N, K,
+                                  int(bool(lower))))

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path through the C ABI (libcokrige_hip.so) against the CPU
+oracle and against the golden fixtures generated from the reference."""
+import numpy as np
+import pytest
+from numpy.linalg import LinAlgError
+
+from oracle import cokrige_oracle as orc
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+HAV, EUC = 0, 1
+
+
+@pytest.fixture(scope="module")
+def native():
+    from sif_xco2_cokriging_amd import native as nat
+    assert nat.device_count() >= 1
+    return nat
+
+
+def handle_for(native, params, metric):
+    p = orc.Params.from_flat(params)
+    h = native.Handle(0)
+    if p.n_procs == 2:
+        h.set_model(2, p.sigma, [p.nu[0, 0], p.nu[0, 1], p.nu[1, 1]],
+                    [p.len_scale[0, 0], p.len_scale[0, 1], p.len_scale[1, 1]], p.nugget, p.rho)
+    else:
+        h.set_model(1, p.sigma, [p.nu[0, 0]] * 3, [p.len_scale[0, 0]] * 3, p.nugget, 0.0)
+    h.set_metric(metric)
+    return h, p
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_mfma_f64_layout(native):
+    """v_mfma_f64_16x16x4_f64: lane l, register r holds D[(l >> 4) + 4 r][l & 15]."""
+    h = native.Handle(0)
+    pr = h.mfma_probe()
+    lane = np.arange(64)[:, None]
+    reg = np.arange(4)[None, :]
+    print("probe rows lane0..3:", pr[:4, :, 0].tolist(), "lane16:", pr[16, :, 0].tolist())
+    assert np.array_equal(pr[:, :, 2], np.full((64, 4), 7))
+    assert np.array_equal(pr[:, :, 1], np.broadcast_to(lane & 15, (64, 4)))
+    assert np.array_equal(pr[:, :, 0], (lane >> 4) + 4 * reg)
+
+
+def test_distance_dense(native):
+    g = load_golden("cov_blocks")
+    h = native.Handle(0)
+    h.set_metric(HAV)
+    d = h.distance_dense(g["A"], g["B"])
+    assert rel(d, g["hav_AB"]) < 1e-13
+    d = h.distance_dense(g["A"], g["A"])
+    assert rel(d, g["hav_AA"]) < 1e-13
+    assert np.array_equal(d == 0, g["hav_AA"] == 0)   # exact zeros where coordinates coincide
+    h.set_metric(EUC)
+    assert rel(h.distance_dense(g["A"], g["B"]), g["euc_AB"]) < 1e-15
+
+
+def test_matern_correlation_grid(native):
+    """rho(h) for every nu of the fixture grid: general K_nu (Temme / CF2) and closed forms."""
+    g = load_golden("kv_grid")
+    for k, nu in enumerate(g["nus"]):
+        h = native.Handle(0)
+        h.set_model(1, [1.0], [nu] * 3, [1.0] * 3, [0.0], 0.0)
+        r = h.cov_lags(0, 0, g["h"], use_nugget=False)
+        ref = g["rho"][k]
+        # scipy's kv itself is only good to ~1e-13 relative around x = 2 (AMOS regime switch);
+        # where rho < 1e-290 the reference has already lost digits to subnormal K_nu
+        big = ref > 1e-290
+        assert np.max(np.abs(r[big] / ref[big] - 1)) < 5e-13, nu
+        assert np.max(np.abs(r[~big] - ref[~big])) < 1e-290
+        h2 = native.Handle(0)
+        h2.set_model(1, [1.0], [nu] * 3, [460.0] * 3, [0.0], 0.0)
+        r = h2.cov_lags(0, 0, g["h"] * 460.0, use_nugget=False)
+        ref = g["rho_len460"][k]
+        big = ref > 1e-290
+        assert np.max(np.abs(r[big] / ref[big] - 1)) < 5e-13, nu
+
+
+@pytest.mark.parametrize("tag", ["A", "B", "R", "S"])
+def test_cov_dense_blocks(native, tag):
+    g = load_golden("cov_blocks")
+    h, p = handle_for(native, g[f"params_{tag}"], HAV)
+    S = g[f"Sigma_{tag}"]
+    nA = len(g["A"])
+    b00 = h.cov_dense(0, 0, g["A"], g["A"])
+    b01 = h.cov_dense(0, 1, g["A"], g["B"])
+    b11 = h.cov_dense(1, 1, g["B"], g["B"])
+    for got, ref in ((b00, S[:nA, :nA]), (b01, S[:nA, nA:]), (b11, S[nA:, nA:])):
+        np.testing.assert_allclose(got, ref, rtol=5e-13, atol=1e-300)
+    for i in (0, 1):
+        c0 = np.vstack([h.cov_dense(i, 0, g["A"], g["G"]) if i == 0 else h.cov_dense(1, 0, g["A"], g["G"]),
+                        h.cov_dense(i, 1, g["B"], g["G"])])
+        np.testing.assert_allclose(c0, g[f"c0_{tag}_{i}"], rtol=5e-13, atol=1e-300)
+
+
+def test_gemm_nt_mfma(native):
+    import torch
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    h = native.Handle(0)
+    for (M, N, K, lower) in ((256, 128, 16, False), (512, 256, 64, False), (768, 192, 64, False),
+                             (1024, 512, 512, True), (256, 64, 64, False)):
+        A = torch.randn(M, K, dtype=torch.float64, device=dev)
+        B = torch.randn(N, K, dtype=torch.float64, device=dev)
+        C = torch.randn(M, N, dtype=torch.float64, device=dev)
+        ref = (C - A @ B.T).cpu().numpy()
+        C0 = C.clone()
+        torch.cuda.synchronize()
+        h.dev_gemm_nt(C.data_ptr(), N, A.data_ptr(), K, B.data_ptr(), K, M, N, K, lower=lower)
+        h.synchronize()
+        got = C.cpu().numpy()
+        if lower:
+            # tiles strictly above the diagonal are skipped (left untouched)
+            BN = 128 if N % 128 == 0 else 64
+            c0 = C0.cpu().numpy()
+            for tm in range(M // 256):
+                for tn in range(N // BN):
+                    blk = (slice(tm * 256, tm * 256 + 256), slice(tn * BN, tn * BN + BN))
+                    if tm * 256 + 255 < tn * BN:
+                        assert np.array_equal(got[blk], c0[blk])
+                    else:
+                        np.testing.assert_allclose(got[blk], ref[blk], rtol=1e-12, atol=1e-11)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
+
+
+def _assembled(native, params, coords, values, metric):
+    h, p = handle_for(native, params, metric)
+    for k in range(p.n_procs):
+        h.set_data(k, coords[k], values[k])
+    h.assemble_joint()
+    return h, p
+
+
+def test_assemble_and_factor_vs_oracle(native):
+    g = load_golden("joint_solve")
+    coords = [g["coords0_A"], g["coords1_A"]]
+    values = [g["values0_A"], g["values1_A"]]
+    h, p = _assembled(native, g["params_A"], coords, values, HAV)
+    N = 400
+    S = orc.joint_cov(p, coords, HAV)
+    low = h.debug_get_lower(N)
+    np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=1e-300)
+    assert h.factor() == 0
+    L = h.debug_get_lower(N)
+    Lref = np.linalg.cholesky(S)
+    assert rel(L, Lref) < 1e-11
+    assert rel(L @ L.T, S) < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["A", "R", "B"])
+def test_joint_predict_fixture(native, tag):
+    g = load_golden("joint_solve")
+    coords = [g[f"coords0_{tag}"], g[f"coords1_{tag}"]]
+    values = [g[f"values0_{tag}"], g[f"values1_{tag}"]]
+    h, p = _assembled(native, g[f"params_{tag}"], coords, values, HAV)
+    assert h.factor() == 0
+    for i in (0, 1):
+        pred, err = h.predict(i, g[f"pcoords_{tag}"])
+        # north-star tolerance: 1e-6 relative to the scipy path; we hold 1e-9
+        assert rel(pred, g[f"pred_{tag}_{i}"]) < 1e-9
+        assert np.max(np.abs(err ** 2 - g[f"pred_err_{tag}_{i}"] ** 2)) < 1e-10
+
+
+def test_kat_simulation_experiment(native):
+    """The reference's one recorded known-answer test (simulation_experiment.ipynb:762-763)."""
+    g = load_golden("kat_simulation_experiment")
+    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [g["values0"], g["values1"]], EUC)
+    assert h.factor() == 0
+    pred, err = h.predict(1, g["pcoords"])
+    assert np.allclose(pred[:4], [1.025, 1.129, 1.177, 1.106], atol=6e-4)
+    assert np.allclose(pred[-3:], [-0.3236, -0.2804, -0.2439], atol=6e-5)
+    assert np.allclose(err[:4], [0.2072, 0.1824, 0.1494, 0.0871], atol=6e-5)
+    assert np.allclose(err[-3:], [0.6993, 0.7249, 0.754], atol=6e-4)
+    # nugget-free, cond(Sigma) ~ 1e7: the oracle's own solver-order noise is ~1e-9
+    assert rel(pred, g["pred"]) < 1e-6
+    assert np.max(np.abs(err - g["pred_err"])) < 1e-6
+    # univariate kriging of process 1 alone (notebook cell 14)
+    hu, pu = _assembled(native, g["params_uni"], [g["coords1"]], [g["values1"]], EUC)
+    assert hu.factor() == 0
+    pred, err = hu.predict(0, g["pcoords"])
+    assert rel(pred, g["pred_uni"]) < 1e-6
+    assert np.max(np.abs(err - g["pred_err_uni"])) < 1e-6
+
+
+def test_not_positive_definite_reports_minor(native):
+    g = load_golden("joint_not_pd")
+    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], HAV)
+    info = h.factor()
+    assert info == int(g["minor"])
+
+
+def test_predictor_class_api(native):
+    """The reference-signature classes end to end (Predictor over MultivariateMatern + MultiField)."""
+    import pandas as pd
+    from sif_xco2_cokriging_amd import fields, joint_prediction, model
+    g = load_golden("joint_solve")
+    mp = model.MaternParams().set_values(g["params_A"])
+    mod = model.MultivariateMatern(params=mp)
+    mf = fields.MultiField([fields.Field(g["coords0_A"], g["values0_A"]), fields.Field(g["coords1_A"], g["values1_A"])])
+    P = joint_prediction.Predictor(mod, mf)
+    pc = pd.DataFrame(g["pcoords_A"], columns=["lat", "lon"])
+    with pytest.warns(UserWarning):   # prediction sites on data sites (fixture rows 0..5)
+        out = P(1, pc, postprocess=False)
+    df = out.to_dataframe().reset_index() if hasattr(out, "to_dataframe") else out.reset_index()
+    df = pc.merge(df, on=["lat", "lon"], how="left")
+    assert rel(df["pred"].values, g["pred_A_1"]) < 1e-9
+    # model mirror
+    hlag = np.array([0.0, 1.0, 50.0, 700.0])
+    po = orc.Params.from_flat(g["params_A"])
+    np.testing.assert_allclose(mod.covariance(0, hlag), orc.covariance(po, 0, hlag), rtol=5e-13)
+    np.testing.assert_allclose(mod.cross_covariance(1, 0, hlag), orc.cross_covariance(po, 0, 1, hlag), rtol=5e-13)
+    # not-PD model raises like scipy's cho_factor
+    g2 = load_golden("joint_not_pd")
+    mod2 = model.MultivariateMatern(params=model.MaternParams().set_values(g2["params"]))
+    mf2 = fields.MultiField([fields.Field(g2["coords0"], np.zeros(260)), fields.Field(g2["coords1"], np.zeros(260))])
+    with pytest.raises(LinAlgError) as e:
+        joint_prediction.Predictor(mod2, mf2)(0, pc, postprocess=False)
+    assert str(e.value) == str(g2["message"])
+
+
+def test_joint_loocv(native):
+    from sif_xco2_cokriging_amd import fields, joint_prediction, model
+    g = load_golden("joint_loocv")
+    mod = model.MultivariateMatern(params=model.MaternParams().set_values(g["params"]))
+    mf = fields.MultiField([fields.Field(g["coords0"], g["values0"]), fields.Field(g["coords1"], g["values1"])])
+    P = joint_prediction.Predictor(mod, mf)
+    df = P.cross_validation(0, postprocess=False)
+    assert rel(df["pred"].values, g["pred_0"]) < 1e-9
+    assert rel(df["pred_err"].values, g["pred_err_0"]) < 1e-9
+    np.testing.assert_allclose(df["residual"].values, g["values0"] - g["pred_0"], rtol=1e-7, atol=1e-9)
