@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cokriging grid-points/s at n_obs = 20k bivariate (BASELINE.json configs[2]).
+
+One step = one pass of the hot path on the GPU(s): assemble Sigma (K1), blocked FP64-MFMA
+Cholesky (K3), assemble c0 (K2), forward substitution + fused prediction / variance reductions
+(K4) for the 8 833-point 0.5-degree CONUS grid.  Coordinates and values are resident in HBM
+before the timed region; only the 141 KB of prediction coordinates and the 141 KB of results
+cross PCIe inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-obs 20000] [--params A|B]
+
+N > 1 is launched by the driver under torch.distributed.run (one rank per GPU, RCCL): Sigma is
+partitioned 1-D block-column-cyclic, panels are broadcast over xGMI at each Cholesky step, the
+prediction points are sharded by rank ("scaling": "strong" -- total work fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD datasheet; the local guide lists no FP64 figure)
+PEAK_HBM_GBS = 8000.0
+
+
+def trailing_update_flops(N, NB=512):
+    """Algorithmic flops of all Cholesky trailing updates (lower triangle only): for panel K the
+    trailing matrix has T = N - (K+1) NB rows; T (T + 1) / 2 entries x 2 NB flops."""
+    tot = 0.0
+    K = 0
+    while True:
+        T = N - (K + 1) * NB
+        if T <= 0:
+            break
+        tot += T * (T + 1) / 2 * 2 * NB
+        K += 1
+    return tot
+
+
+def aux_update_flops(N, m, NB=512):
+    tot = 0.0
+    K = 0
+    while True:
+        T = N - (K + 1) * NB
+        if T <= 0:
+            break
+        tot += 2.0 * (m + 1) * T * NB
+        K += 1
+    return tot
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (numpy/scipy restatement of the reference path) timed on this host's cores on a
+    bounded sample of the same workload: same lattice, same model, same 0.5-degree grid
+    resolution, n = 1 500 per process (N = 3 000) and the first 2 000 grid points."""
+    import numpy as np
+    from oracle import cokrige_oracle as orc
+    from sif_xco2_cokriging_amd import synth
+    n, m = 1500, 2000
+    pb = synth.conus_problem(n, seed=20003)
+    p = orc.Params.from_flat(pb["params"])
+    t0 = time.perf_counter()
+    orc.joint_predict(p, pb["coords"], pb["values"], pb["pcoords"][:m], 0, pb["metric"])
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "grid-points/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle joint_predict, n_obs={n}/process (N={2*n}), m={m} grid points, {dt:.1f} s wall; "
+                      f"numpy/scipy with BLAS threads = all {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-obs", type=int, default=20000)
+    ap.add_argument("--params", default="A")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    from sif_xco2_cokriging_amd import native, synth
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    params = synth.SET_A if args.params == "A" else synth.SET_B
+    pb = synth.conus_problem(args.n_obs, seed=20003, params=params)
+    n = args.n_obs
+    N = 2 * n
+    m = len(pb["pcoords"])
+
+    h = native.Handle(local_rank)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    pv = pb["params"]
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(pb["metric"])
+    for k in range(2):
+        h.set_data(k, pb["coords"][k], pb["values"][k])
+
+    if world == 1:
+        h.set_option("time_gemm", 1)
+
+        def step():
+            h.assemble_joint()
+            info = h.factor()
+            if info != 0:
+                raise RuntimeError(f"Sigma not positive definite at minor {info}")
+            return h.predict(0, pb["pcoords"])
+    else:
+        from sif_xco2_cokriging_amd import distributed
+        runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank))
+        runner.prepare(m_total=m)
+
+        def step():
+            return runner.predict(0, pb["pcoords"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    tim = []
+    for _ in range(args.steps):
+        pred, err = step()
+        tim.append(h.timings())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        out = {
+            "metric": "cokriging grid-points/s at n_obs=20k bivariate",
+            "value": m / (ms_per_step / 1e3),
+            "unit": "grid-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: n_obs={n}/process (N={N}) SIF+XCO2-like residuals on the 0.05-degree "
+                                   f"CONUS lattice, haversine, full 2n x 2n solve, {m}-point 0.5-degree grid, "
+                                   f"Matern set {args.params}",
+                       "n_obs": n, "N": N, "m": m, "params": pv, "partition": f"block-column-cyclic x{world}"},
+        }
+        if world == 1:
+            tl = tim[-1]
+            flops = trailing_update_flops(N)
+            syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
+            out["roofline"] = {
+                "kernel": "k_syrk_panels (Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
+                "algorithmic_flops_per_step": flops,
+            }
+            aux_s = np.mean([t["aux_gemm_ms"] for t in tim]) / 1e3
+            cov_bytes = 8.0 * (N * (N + 1) / 2)
+            out["stages"] = {
+                "assemble_sigma_ms": tl["assemble_sigma_ms"], "factor_ms": tl["factor_ms"],
+                "assemble_c0_ms": tl["assemble_aux_ms"], "solve_ms": tl["solve_ms"], "reduce_ms": tl["reduce_ms"],
+                "cholesky_tflops": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12,
+                "cholesky_frac_of_mfma_peak": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                "solve_gemm_tflops": aux_update_flops(N, m) / aux_s / 1e12 if aux_s > 0 else None,
+                "cov_assembly_GBs": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9,
+                "cov_assembly_frac_of_hbm_peak": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9 / PEAK_HBM_GBS,
+            }
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,9 @@ int ck_set_stream(ck_handle* h, void* hip_stream);
  * Without an arena the library allocates with hipMalloc.  Must precede ck_set_data. */
 int ck_set_arena(ck_handle* h, void* dev_base, int64_t nbytes);
 int ck_synchronize(ck_handle* h);
+/* Device bytes the handle will allocate for the data set so far, the current partition and
+ * `m` prediction points (size an arena with it; call after ck_set_data/ck_set_partition). */
+int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out);
 
 /* ---- model and data ------------------------------------------------------- */
 /* Matern parameters in the reference's order (src/model.py:122-130,145-152):
@@ -127,7 +130,9 @@ int ck_debug_get_lower(ck_handle* h, double* out_host, int64_t n);
 int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* Stage timings of the last calls in milliseconds (HIP events):
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
- * [5] trailing-update GEMM launches total inside factor, [6] number of those launches. */
+ * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
+ * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
+ * trailing updates of the last ck_predict. */
 int ck_timings(ck_handle* h, double* out, int n);
 /* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events. */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);

@@ -82,7 +82,7 @@ struct ck_handle {
     double* d_pcoords = nullptr;
     // scratch for dense calls
     // timings
-    double t_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool time_gemm = false;
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
@@ -421,6 +421,20 @@ static void gemm_timed_end(ck_handle* h) {
     h->gemm_ev_used++;
 }
 
+// sum the event pairs recorded since the last reset into t_ms[slot], t_ms[slot + 1]
+static void gemm_timed_collect(ck_handle* h, int slot) {
+    if (!h->time_gemm) return;
+    double tot = 0;
+    for (size_t e = 0; e < h->gemm_ev_used; ++e) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, h->gemm_ev[e].a, h->gemm_ev[e].b);
+        tot += t;
+    }
+    h->t_ms[slot] = tot;
+    h->t_ms[slot + 1] = (double)h->gemm_ev_used;
+    h->gemm_ev_used = 0;
+}
+
 extern "C" int ck_panel_factor(ck_handle* h, int K) {
     CHKH(h);
     if (!h->assembled) return fail("ck_assemble_joint has not been called");
@@ -509,16 +523,7 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[1] = ms;
-    if (h->time_gemm) {
-        double tot = 0;
-        for (size_t e = 0; e < h->gemm_ev_used; ++e) {
-            float t = 0;
-            (void)hipEventElapsedTime(&t, h->gemm_ev[e].a, h->gemm_ev[e].b);
-            tot += t;
-        }
-        h->t_ms[5] = tot;
-        h->t_ms[6] = (double)h->gemm_ev_used;
-    }
+    gemm_timed_collect(h, 5);
     h->factored = true;
     return 0;
 }
@@ -592,6 +597,7 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     if (h->world != 1) return fail("ck_predict is the single-process form");
     if (!h->factored) return fail("ck_factor has not been called");
     if (ck_aux_begin(h, i, pcoords, m)) return -1;
+    h->gemm_ev_used = 0;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -603,6 +609,7 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     h->t_ms[3] = ms;
+    gemm_timed_collect(h, 7);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return 0;
@@ -648,6 +655,24 @@ extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
     return 0;
 }
 
+extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
+    CHKH(h);
+    for (int k = 0; k < h->n_procs; ++k)
+        if (!h->data_set[k]) return fail("ck_set_data missing for process " + std::to_string(k));
+    const int64_t N = h->n[0] + (h->n_procs == 2 ? h->n[1] : 0);
+    const int64_t Np = roundup(N, CK_NB);
+    const int nK = (int)(Np / CK_NB);
+    auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    int64_t tot = 4 * al(Np * 8);
+    for (int K = h->rank; K < nK; K += h->world) tot += al((Np - (int64_t)K * CK_NB) * CK_NB * 8);
+    tot += al((int64_t)nK * sizeof(double*));
+    if (h->world > 1) tot += 2 * al(Np * CK_NB * 8);
+    const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
+    tot += al(mpad * Np * 8) + al(3 * mpad * 8) + 2 * al(2 * mpad * 8);
+    *out = tot + 4096;
+    return 0;
+}
+
 extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     CHKH(h);
     if (!name) return fail("null option name");
@@ -660,7 +685,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
 
 extern "C" int ck_timings(ck_handle* h, double* out, int n) {
     CHKH(h);
-    for (int k = 0; k < n && k < 8; ++k) out[k] = h->t_ms[k];
+    for (int k = 0; k < n && k < 12; ++k) out[k] = h->t_ms[k];
     return 0;
 }
 

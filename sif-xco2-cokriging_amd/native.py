@@ -31,6 +31,7 @@ _PROTOS = {
     "ck_set_stream": [c_void_p, c_void_p],
     "ck_set_arena": [c_void_p, c_void_p, c_int64],
     "ck_synchronize": [c_void_p],
+    "ck_estimate_bytes": [c_void_p, c_int64, POINTER(c_int64)],
     "ck_set_model": [c_void_p, c_int, _dp, _dp, _dp, _dp, c_double],
     "ck_set_metric": [c_void_p, c_int],
     "ck_set_partition": [c_void_p, c_int, c_int],
@@ -67,6 +68,28 @@ def exported_names():
     return ["ck_last_error"] + list(_PROTOS)
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (SONAME libamdhip64.so.7, same as /opt/rocm's) but load it by the unversioned file name,
+    so whichever of {torch, this library} comes second would otherwise map a SECOND runtime,
+    which then sees no GPU.  When torch is installed, map its copy first (by path, global):
+    our NEEDED libamdhip64.so.7 and torch's later dlopen both resolve to it."""
+    import importlib.util
+    import sys
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -74,6 +97,7 @@ def lib():
             raise NativeError(
                 f"{LIB_PATH} is missing: build it with `python sif-xco2-cokriging_amd/build_native.py` "
                 "(hipcc, gfx950).  There is no CPU fallback.")
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         L.ck_last_error.restype = c_char_p
         L.ck_last_error.argtypes = []
@@ -133,6 +157,11 @@ class Handle:
     def set_arena(self, dev_ptr: int, nbytes: int, keepalive=None):
         self._keep.append(keepalive)
         _chk(lib().ck_set_arena(self._h, c_void_p(dev_ptr), int(nbytes)))
+
+    def estimate_bytes(self, m: int) -> int:
+        out = c_int64(0)
+        _chk(lib().ck_estimate_bytes(self._h, int(m), byref(out)))
+        return out.value
 
     def synchronize(self):
         _chk(lib().ck_synchronize(self._h))
@@ -244,9 +273,10 @@ class Handle:
         return out.reshape(64, 4, 3)
 
     def timings(self):
-        out = np.zeros(8)
-        _chk(lib().ck_timings(self._h, _p(out), 8))
-        keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "gemm_ms", "gemm_launches"]
+        out = np.zeros(12)
+        _chk(lib().ck_timings(self._h, _p(out), 12))
+        keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
+                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):
