@@ -122,6 +122,22 @@ int ck_aux_finish(ck_handle* h, double* pred_host, double* pred_err_host);
 /* info flag of the factorisation so far (synchronises). */
 int ck_factor_info(ck_handle* h, int64_t* info);
 
+/* ---- empirical (cross-)semivariogram / covariogram: src/fields.py:192-232, 378-403 ----- */
+/* Fields i and j: coords (n x 2), residuals = values minus their mean (src/fields.py:380).
+ * same != 0: marginal variogram, strict upper triangle of the i-i pairs (:195-199; j args ignored);
+ * else all n_i * n_j pairs (:200-203).  Uses the handle's metric. */
+int ck_vario_begin(ck_handle* h, const double* coords_i_host, const double* resid_i_host, int64_t n_i,
+                   const double* coords_j_host, const double* resid_j_host, int64_t n_j, int same);
+/* Pass 1: lo = smallest positive and hi = largest pair distance among pairs with d <= max_dist
+ * (src/fields.py:212, 394-395); n_positive = 0 if there is no such pair (lo, hi = NaN). */
+int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64_t* n_positive);
+/* Pass 2: per-bin sum of cloud values and pair count for bins (e_b, e_b+1], first bin [0, e_1]
+ * (pd.cut(include_lowest=True), :214-222); edges[0] must be 0; at most 36 bins.
+ * cloud = 0.5 (a - b)^2, or a * b when covariogram != 0 (:378-386). */
+int ck_vario_bin(ck_handle* h, double max_dist, const double* edges_host, int n_edges, int covariogram,
+                 double* sums_host, int64_t* counts_host);
+int ck_vario_end(ck_handle* h);
+
 /* ---- diagnostics ------------------------------------------------------------- */
 /* Copy the locally owned part of Sigma / L back as a dense (N x N) lower triangle
  * (upper triangle zero-filled); small N only (tests). */
@@ -132,7 +148,7 @@ int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
- * trailing updates of the last ck_predict. */
+ * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events. */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);

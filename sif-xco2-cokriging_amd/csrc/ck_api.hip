@@ -80,7 +80,16 @@ struct ck_handle {
     int64_t p_cap = 0;
     double *d_pred = nullptr, *d_err = nullptr;
     double* d_pcoords = nullptr;
-    // scratch for dense calls
+    // empirical variogram state (ck_vario_*)
+    std::vector<double> vg_ci, vg_cj;   // host copies of the coordinates (extreme pairs are re-evaluated)
+    double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
+    int64_t vg_ni = 0, vg_nj = 0;
+    int vg_same = 0, vg_grid = 0;
+    void* vg_part = nullptr;
+    double* vg_psum = nullptr;
+    unsigned long long* vg_pcnt = nullptr;
+    double* vg_out = nullptr;          // thr[38] | sums[36] | counts[36] (as 8-byte words)
+    unsigned char* vg_lut = nullptr;
     // timings
     double t_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool time_gemm = false;
@@ -143,10 +152,13 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
     return 0;
 }
 
+static void vario_free(ck_handle* h);
+
 extern "C" int ck_destroy(ck_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    vario_free(h);
     for (void* p : h->owned) (void)hipFree(p);
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_info);
@@ -612,6 +624,168 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     gemm_timed_collect(h, 7);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// empirical (cross-)variogram: src/fields.py:192-232
+// ---------------------------------------------------------------------------------------
+static void vario_free(ck_handle* h) {
+    void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut};
+    for (void* p : ps)
+        if (p) (void)hipFree(p);
+    h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
+    h->vg_part = nullptr;
+    h->vg_psum = nullptr;
+    h->vg_pcnt = nullptr;
+    h->vg_out = nullptr;
+    h->vg_lut = nullptr;
+}
+
+static int vario_upload(ck_handle* h, const double* coords, const double* vals, int64_t n, double** u, double** v) {
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)u, 3 * n * 8));
+    HIPCHK(hipMalloc((void**)v, n * 8));
+    HIPCHK(hipMalloc((void**)&tmp, 2 * n * 8));
+    HIPCHK(hipMemcpyAsync(tmp, coords, 2 * n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(*v, vals, n * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_vario_prep(h->stream, tmp, n, h->metric, *u, *u + n, *u + 2 * n);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+    return 0;
+}
+
+extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double* resid_i, int64_t n_i,
+                              const double* coords_j, const double* resid_j, int64_t n_j, int same) {
+    CHKH(h);
+    if (n_i <= 0 || !coords_i || !resid_i) return fail("bad field i");
+    if (!same && (n_j <= 0 || !coords_j || !resid_j)) return fail("bad field j");
+    vario_free(h);
+    h->vg_same = same ? 1 : 0;
+    h->vg_ni = n_i;
+    h->vg_ci.assign(coords_i, coords_i + 2 * n_i);
+    if (vario_upload(h, coords_i, resid_i, n_i, &h->vg_iu, &h->vg_iv)) return -1;
+    if (same) {
+        h->vg_nj = n_i;
+        h->vg_cj = h->vg_ci;
+        h->vg_ju = h->vg_iu;
+        h->vg_jv = h->vg_iv;
+    } else {
+        h->vg_nj = n_j;
+        h->vg_cj.assign(coords_j, coords_j + 2 * n_j);
+        if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv)) return -1;
+    }
+    h->vg_grid = ck_vario_grid(h->vg_ni, h->vg_nj);
+    HIPCHK(hipMalloc(&h->vg_part, h->vg_grid * sizeof(CkVarioExt)));
+    HIPCHK(hipMalloc((void**)&h->vg_psum, (size_t)h->vg_grid * CK_VG_MAXBINS * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_pcnt, (size_t)h->vg_grid * CK_VG_MAXBINS * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_out, (CK_VG_MAXBINS + 2 + 2 * CK_VG_MAXBINS) * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_lut, CK_VG_LUT));
+    return 0;
+}
+
+// distance -> the monotone r the kernels compare (see ck_vario.hip)
+static double vario_r_of_dist(int metric, double d) {
+    if (metric == CK_METRIC_EUCLID) return d * d;
+    const long double a = (long double)d / (2.0L * CK_EARTH_RADIUS_KM);
+    if (a >= 1.57079632679489661923L) return 1.0 + 1e-12;   // beyond half the circumference: everything
+    const long double sn = sinl(a);
+    return (double)(sn * sn);
+}
+
+extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64_t* n_positive) {
+    CHKH(h);
+    if (!h->vg_iu) return fail("ck_vario_begin has not been called");
+    const double rcap = vario_r_of_dist(h->metric, max_dist);
+    ck_launch_vario_extent(h->stream, h->vg_grid, h->metric, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj,
+                           rcap, h->vg_part);
+    HIPCHK(hipGetLastError());
+    std::vector<CkVarioExt> part(h->vg_grid);
+    HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    CkVarioExt best = part[0];
+    for (int g = 1; g < h->vg_grid; ++g) {
+        if (part[g].rmin < best.rmin) {
+            best.rmin = part[g].rmin;
+            best.imin = part[g].imin;
+            best.jmin = part[g].jmin;
+        }
+        if (part[g].rmax > best.rmax) {
+            best.rmax = part[g].rmax;
+            best.imax = part[g].imax;
+            best.jmax = part[g].jmax;
+        }
+    }
+    *n_positive = (best.imin >= 0) ? 1 : 0;
+    *lo = *hi = NAN;
+    // the two extreme pairs again, with the full-accuracy distance formula (on the device)
+    if (best.imin >= 0) {
+        double d = 0;
+        if (dense_common(h, 0, 0, 1, &h->vg_ci[2 * best.imin], 1, &h->vg_cj[2 * best.jmin], 1, &d)) return -1;
+        *lo = d;
+    }
+    if (best.imax >= 0) {
+        double d = 0;
+        if (dense_common(h, 0, 0, 1, &h->vg_ci[2 * best.imax], 1, &h->vg_cj[2 * best.jmax], 1, &d)) return -1;
+        *hi = d;
+    }
+    return 0;
+}
+
+extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, int n_edges, int covariogram,
+                            double* sums, int64_t* counts) {
+    CHKH(h);
+    if (!h->vg_iu) return fail("ck_vario_begin has not been called");
+    const int nb = n_edges - 1;
+    if (nb < 1 || nb > CK_VG_MAXBINS) return fail("n_bins must be between 1 and " + std::to_string(CK_VG_MAXBINS));
+    for (int b = 0; b < nb; ++b)
+        if (!(edges[b + 1] > edges[b])) return fail("bin edges must increase");
+    if (edges[0] != 0.0) return fail("first bin edge must be 0 (src/fields.py:402)");
+    double thr[CK_VG_MAXBINS + 2];
+    for (int b = 0; b <= nb; ++b) thr[b] = vario_r_of_dist(h->metric, edges[b]);
+    thr[0] = 0.0;
+    const double cell = thr[nb] / CK_VG_LUT;
+    unsigned char lut[CK_VG_LUT];
+    {
+        int b = 0;
+        for (int c = 0; c < CK_VG_LUT; ++c) {
+            const double lo_end = c * cell;
+            while (b + 1 < nb && thr[b + 1] <= lo_end) ++b;
+            lut[c] = (unsigned char)b;
+            // at most two edges may fall inside one cell (the kernel fixes up twice)
+            int inside = 0;
+            for (int e = b + 1; e <= nb && thr[e] < lo_end + cell; ++e) ++inside;
+            if (inside > 2 && c + 1 < CK_VG_LUT) return fail("variogram bins too narrow near zero for the r-space lookup");
+        }
+    }
+    const double rcap = vario_r_of_dist(h->metric, max_dist);
+    double* d_thr = h->vg_out;
+    double* d_sums = h->vg_out + CK_VG_MAXBINS + 2;
+    long long* d_cnt = (long long*)(h->vg_out + 2 * CK_VG_MAXBINS + 2);
+    HIPCHK(hipMemcpyAsync(d_thr, thr, (nb + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vg_lut, lut, CK_VG_LUT, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    ck_launch_vario_bin(h->stream, h->vg_grid, h->metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv,
+                        h->vg_ni, h->vg_ju, h->vg_jv, h->vg_nj, rcap, nb, d_thr, h->vg_lut, 1.0 / cell, h->vg_psum,
+                        h->vg_pcnt, d_sums, d_cnt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    long long cnt[CK_VG_MAXBINS];
+    HIPCHK(hipMemcpyAsync(sums, d_sums, nb * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cnt, d_cnt, nb * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < nb; ++b) counts[b] = cnt[b];
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[9] = ms;
+    return 0;
+}
+
+extern "C" int ck_vario_end(ck_handle* h) {
+    CHKH(h);
+    vario_free(h);
     return 0;
 }
 

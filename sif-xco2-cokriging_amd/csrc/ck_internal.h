@@ -56,3 +56,21 @@ void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const
 void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
                            double c0, double* pred, double* err);
 void ck_launch_mfma_probe(hipStream_t s, int32_t* out);
+
+// ---- empirical variogram (ck_vario.hip) ----------------------------------------------------
+#define CK_VG_MAXBINS 36
+#define CK_VG_LUT 8192
+struct CkVarioExt {
+    double rmin, rmax;
+    long long imin, jmin, imax, jmax;
+};
+void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int metric, double* u0, double* u1,
+                          double* u2);
+int ck_vario_grid(int64_t ni, int64_t nj);
+// iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]
+void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
+                            const double* ju, int64_t nj, double rcap, void* part);
+void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
+                         const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
+                         int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
+                         unsigned long long* part_cnt, double* sums, long long* counts);

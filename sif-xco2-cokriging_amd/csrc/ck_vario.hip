@@ -1,0 +1,295 @@
+// ck_vario.hip -- empirical (cross-)semivariogram / covariogram: pairwise lag binning.
+//
+// Replaces MultiField._variogram_cloud + get_variogram's pd.cut/groupby
+// (src/fields.py:192-232, 378-386) without the dense n_i x n_j distance and cloud matrices:
+// every pair is visited in registers, binned, and accumulated into a per-lane histogram in LDS.
+//
+// Distance: bins are decided on a monotone function r of the distance, so the inner loop needs
+// no sqrt / asin / sin:
+//   haversine  r = sin^2(theta / 2) = |u_i - u_j|^2 / 4   with u the unit vectors of the sites
+//              (the same r as sklearn's rdist, src/fields.py:336; d = 2 R asin(sqrt(r)));
+//   Euclidean  r = dx^2 + dy^2.
+// Bin edges (data dependent, src/fields.py:389-403) are transformed to r-space on the host.
+// Two passes, as the reference needs lo = min positive and hi = max retained distance before it
+// can place the edges: pass 1 finds the two extreme pairs (their distances are then recomputed
+// with the full-accuracy formula), pass 2 bins.
+//
+// Pass 2 layout: one workgroup = 256 "i" points in registers x chunks of 1024 "j" points staged
+// in LDS and broadcast; each lane owns a private histogram (sum f64 + count u32 per bin) in LDS,
+// laid out [bin][lane] so that the 64 lanes of a wave always hit distinct banks whatever bins
+// they choose: no atomics, no conflicts, deterministic sums.  Workgroups walk the tile list with
+// a fixed stride and write one partial histogram each; a second kernel adds the partials in a
+// fixed order.
+#include "ck_internal.h"
+
+#define VG_TPB 256
+#define VG_JCHUNK 1024
+#define VG_MAXBINS 36
+#define VG_LUT 8192
+
+struct VarioPartialExt {
+    double rmin, rmax;
+    long long imin, jmin, imax, jmax;
+};
+
+// per-site: haversine -> unit vector (x, y, z); Euclid -> (x, y, 0)
+__global__ void k_vario_prep(const double* __restrict__ coords, long n, int metric, double* __restrict__ u0,
+                             double* __restrict__ u1, double* __restrict__ u2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = coords[2 * i], b = coords[2 * i + 1];
+    if (metric == CK_METRIC_HAVERSINE) {
+        const double lat = a * CK_DEG2RAD, lon = b * CK_DEG2RAD;
+        const double cl = cos(lat);
+        u0[i] = cl * cos(lon);
+        u1[i] = cl * sin(lon);
+        u2[i] = sin(lat);
+    } else {
+        u0[i] = a;
+        u1[i] = b;
+        u2[i] = 0.0;
+    }
+}
+
+__device__ __forceinline__ double pair_r(int metric, double ax, double ay, double az, double bx, double by,
+                                         double bz) {
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    const double q = dx * dx + dy * dy + dz * dz;
+    return metric == CK_METRIC_HAVERSINE ? 0.25 * q : q;
+}
+
+// tile t -> (I block, J chunk).  same != 0: only chunks that reach the strict upper triangle.
+struct TileMap {
+    long nI, nJ;
+};
+
+// ---- pass 1: extreme pairs ------------------------------------------------------------------------
+__global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, const double* __restrict__ iu0,
+                                                          const double* __restrict__ iu1,
+                                                          const double* __restrict__ iu2, long ni,
+                                                          const double* __restrict__ ju0,
+                                                          const double* __restrict__ ju1,
+                                                          const double* __restrict__ ju2, long nj, double rcap,
+                                                          VarioPartialExt* __restrict__ part) {
+    __shared__ double sj[3][VG_JCHUNK];
+    __shared__ double red_r[VG_TPB];
+    __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
+    const int tid = threadIdx.x;
+    const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
+    double rmin = 1e300, rmax = -1.0;
+    long long imin = -1, jmin = -1, imax = -1, jmax = -1;
+    for (long t = blockIdx.x; t < nI * nJ; t += gridDim.x) {
+        const long bi = t / nJ, bj = t - bi * nJ;
+        const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
+        if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
+        __syncthreads();
+        for (int k = tid; k < VG_JCHUNK; k += VG_TPB) {
+            const long j = j0 + k;
+            const bool ok = j < nj;
+            sj[0][k] = ok ? ju0[j] : 0.0;
+            sj[1][k] = ok ? ju1[j] : 0.0;
+            sj[2][k] = ok ? ju2[j] : 0.0;
+        }
+        __syncthreads();
+        const long i = i0 + tid;
+        if (i < ni) {
+            const double ax = iu0[i], ay = iu1[i], az = iu2[i];
+            const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
+            long kbeg = 0;
+            if (same) {
+                kbeg = i + 1 - j0;
+                if (kbeg < 0) kbeg = 0;
+            }
+            for (long k = kbeg; k < jend; ++k) {
+                const double r = pair_r(metric, ax, ay, az, sj[0][k], sj[1][k], sj[2][k]);
+                if (r <= rcap) {
+                    if (r > rmax) {
+                        rmax = r;
+                        imax = i;
+                        jmax = j0 + k;
+                    }
+                    if (r > 0.0 && r < rmin) {
+                        rmin = r;
+                        imin = i;
+                        jmin = j0 + k;
+                    }
+                }
+            }
+        }
+    }
+    // workgroup reduction (min)
+    __syncthreads();
+    red_r[tid] = rmin;
+    red_i[tid] = imin;
+    red_j[tid] = jmin;
+    __syncthreads();
+    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s && red_r[tid + s] < red_r[tid]) {
+            red_r[tid] = red_r[tid + s];
+            red_i[tid] = red_i[tid + s];
+            red_j[tid] = red_j[tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[blockIdx.x].rmin = red_r[0];
+        part[blockIdx.x].imin = red_i[0];
+        part[blockIdx.x].jmin = red_j[0];
+    }
+    __syncthreads();
+    red_r[tid] = rmax;
+    red_i[tid] = imax;
+    red_j[tid] = jmax;
+    __syncthreads();
+    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s && red_r[tid + s] > red_r[tid]) {
+            red_r[tid] = red_r[tid + s];
+            red_i[tid] = red_i[tid + s];
+            red_j[tid] = red_j[tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[blockIdx.x].rmax = red_r[0];
+        part[blockIdx.x].imax = red_i[0];
+        part[blockIdx.x].jmax = red_j[0];
+    }
+}
+
+// ---- pass 2: binning ---------------------------------------------------------------------------------
+// thr[0..nb]: r-space edges (thr[0] = 0).  Pair belongs to bin b if thr[b] < r <= thr[b+1]; r == 0
+// goes to bin 0 (pd.cut include_lowest, src/fields.py:214-216).  lut[c] = bin of the lower end of
+// r-cell c (cells uniform in r up to thr[nb]); at most one edge per cell is assumed by the +1 fix-up,
+// which the host guarantees by choosing VG_LUT cells >= 4 / (narrowest bin in r-space).
+__global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int covariogram,
+                                                       const double* __restrict__ iu0,
+                                                       const double* __restrict__ iu1,
+                                                       const double* __restrict__ iu2,
+                                                       const double* __restrict__ iv, long ni,
+                                                       const double* __restrict__ ju0,
+                                                       const double* __restrict__ ju1,
+                                                       const double* __restrict__ ju2,
+                                                       const double* __restrict__ jv, long nj, double rcap,
+                                                       int nb, const double* __restrict__ thr,
+                                                       const unsigned char* __restrict__ lut, double inv_cell,
+                                                       double* __restrict__ part_sum,
+                                                       unsigned long long* __restrict__ part_cnt) {
+    __shared__ double sj[4][VG_JCHUNK];
+    __shared__ double hsum[VG_MAXBINS][VG_TPB];
+    __shared__ unsigned int hcnt[VG_MAXBINS][VG_TPB];
+    __shared__ double sthr[VG_MAXBINS + 2];
+    __shared__ unsigned char slut[VG_LUT];
+    const int tid = threadIdx.x;
+    for (int b = 0; b < nb; ++b) {
+        hsum[b][tid] = 0.0;
+        hcnt[b][tid] = 0u;
+    }
+    for (int k = tid; k <= nb; k += VG_TPB) sthr[k] = thr[k];
+    for (int k = tid; k < VG_LUT; k += VG_TPB) slut[k] = lut[k];
+    const double rtop = thr[nb];
+    const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
+    // per-lane 64-bit count spill: hcnt is 32-bit, a lane sees at most nJ * VG_JCHUNK pairs per I block
+    for (long t = blockIdx.x; t < nI * nJ; t += gridDim.x) {
+        const long bi = t / nJ, bj = t - bi * nJ;
+        const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
+        if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
+        __syncthreads();
+        for (int k = tid; k < VG_JCHUNK; k += VG_TPB) {
+            const long j = j0 + k;
+            const bool ok = j < nj;
+            sj[0][k] = ok ? ju0[j] : 0.0;
+            sj[1][k] = ok ? ju1[j] : 0.0;
+            sj[2][k] = ok ? ju2[j] : 0.0;
+            sj[3][k] = ok ? jv[j] : 0.0;
+        }
+        __syncthreads();
+        const long i = i0 + tid;
+        if (i < ni) {
+            const double ax = iu0[i], ay = iu1[i], az = iu2[i], av = iv[i];
+            const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
+            long kbeg = 0;
+            if (same) {
+                kbeg = i + 1 - j0;
+                if (kbeg < 0) kbeg = 0;
+            }
+            for (long k = kbeg; k < jend; ++k) {
+                const double r = pair_r(metric, ax, ay, az, sj[0][k], sj[1][k], sj[2][k]);
+                if (r <= rcap && r <= rtop) {
+                    int c = (int)(r * inv_cell);
+                    c = c < VG_LUT - 1 ? c : VG_LUT - 1;
+                    int b = slut[c];
+                    b += (r > sthr[b + 1]) ? 1 : 0;     // up to two edges inside one r-cell
+                    b = b < nb - 1 ? b : nb - 1;
+                    b += (r > sthr[b + 1]) ? 1 : 0;
+                    b = b < nb - 1 ? b : nb - 1;
+                    const double bv = sj[3][k];
+                    double cl;
+                    if (covariogram) {
+                        cl = av * bv;                 // fields.py:382-383
+                    } else {
+                        const double df = av - bv;    // fields.py:384-385
+                        cl = 0.5 * (df * df);
+                    }
+                    hsum[b][tid] += cl;
+                    hcnt[b][tid] += 1u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // reduce the 256 private histograms: thread b sums bin b in lane order (deterministic)
+    if (tid < nb) {
+        double s = 0.0;
+        unsigned long long c = 0;
+        for (int l = 0; l < VG_TPB; ++l) {
+            s += hsum[tid][(l + tid) & (VG_TPB - 1)];   // skewed start: bank-conflict free, fixed order per bin
+            c += hcnt[tid][(l + tid) & (VG_TPB - 1)];
+        }
+        part_sum[(long)blockIdx.x * VG_MAXBINS + tid] = s;
+        part_cnt[(long)blockIdx.x * VG_MAXBINS + tid] = c;
+    }
+}
+
+__global__ void k_vario_final(const double* __restrict__ part_sum, const unsigned long long* __restrict__ part_cnt,
+                              int nparts, int nb, double* __restrict__ sums, long long* __restrict__ counts) {
+    const int b = threadIdx.x;
+    if (b >= nb) return;
+    double s = 0.0;
+    unsigned long long c = 0;
+    for (int p = 0; p < nparts; ++p) {
+        s += part_sum[(long)p * VG_MAXBINS + b];
+        c += part_cnt[(long)p * VG_MAXBINS + b];
+    }
+    sums[b] = s;
+    counts[b] = (long long)c;
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------------
+void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int metric, double* u0, double* u1,
+                          double* u2) {
+    if (n <= 0) return;
+    k_vario_prep<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(coords, n, metric, u0, u1, u2);
+}
+
+int ck_vario_grid(int64_t ni, int64_t nj) {
+    const int64_t nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
+    int64_t tiles = nI * nJ;
+    if (tiles < 1) tiles = 1;
+    return (int)(tiles < 2048 ? tiles : 2048);
+}
+
+void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
+                            const double* ju, int64_t nj, double rcap, void* part) {
+    k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj,
+                                                       ju + 2 * nj, nj, rcap, (VarioPartialExt*)part);
+}
+
+void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
+                         const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
+                         int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
+                         unsigned long long* part_cnt, double* sums, long long* counts) {
+    k_vario_bin<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, covariogram, iu, iu + ni, iu + 2 * ni, iv, ni, ju,
+                                                    ju + nj, ju + 2 * nj, jv, nj, rcap, nb, thr, lut, inv_cell,
+                                                    part_sum, part_cnt);
+    k_vario_final<<<dim3(1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, sums, counts);
+}

@@ -50,6 +50,10 @@ _PROTOS = {
     "ck_panel_apply": [c_void_p, c_int, c_int],
     "ck_aux_finish": [c_void_p, _dp, _dp],
     "ck_factor_info": [c_void_p, POINTER(c_int64)],
+    "ck_vario_begin": [c_void_p, _dp, _dp, c_int64, _dp, _dp, c_int64, c_int],
+    "ck_vario_extent": [c_void_p, c_double, _dp, _dp, POINTER(c_int64)],
+    "ck_vario_bin": [c_void_p, c_double, _dp, c_int, c_int, _dp, POINTER(c_int64)],
+    "ck_vario_end": [c_void_p],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
@@ -261,6 +265,32 @@ class Handle:
         _chk(lib().ck_factor_info(self._h, byref(info)))
         return info.value
 
+    # -- empirical variogram ------------------------------------------------------------------------
+    def vario_begin(self, coords_i, resid_i, coords_j=None, resid_j=None):
+        ci, ri = _f64(coords_i, 2), _f64(resid_i).ravel()
+        if coords_j is None:
+            _chk(lib().ck_vario_begin(self._h, _p(ci), _p(ri), ci.shape[0], None, None, 0, 1))
+        else:
+            cj, rj = _f64(coords_j, 2), _f64(resid_j).ravel()
+            _chk(lib().ck_vario_begin(self._h, _p(ci), _p(ri), ci.shape[0], _p(cj), _p(rj), cj.shape[0], 0))
+
+    def vario_extent(self, max_dist):
+        lo, hi, npos = c_double(0), c_double(0), c_int64(0)
+        _chk(lib().ck_vario_extent(self._h, float(max_dist), byref(lo), byref(hi), byref(npos)))
+        return lo.value, hi.value, npos.value
+
+    def vario_bin(self, max_dist, edges, covariogram=False):
+        e = _f64(edges).ravel()
+        nb = e.size - 1
+        sums = np.empty(nb)
+        counts = np.empty(nb, dtype=np.int64)
+        _chk(lib().ck_vario_bin(self._h, float(max_dist), _p(e), e.size, int(bool(covariogram)), _p(sums),
+                                counts.ctypes.data_as(POINTER(c_int64))))
+        return sums, counts
+
+    def vario_end(self):
+        _chk(lib().ck_vario_end(self._h))
+
     # -- diagnostics -----------------------------------------------------------------------------
     def debug_get_lower(self, n):
         out = np.empty((n, n))
@@ -276,7 +306,7 @@ class Handle:
         out = np.zeros(12)
         _chk(lib().ck_timings(self._h, _p(out), 12))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
-                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches"]
+                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):

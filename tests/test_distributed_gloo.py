@@ -1,0 +1,93 @@
+"""world_size-2 (and 3) runs of the multi-process joint predictor on the gloo backend (CPU):
+covers panel ownership, the broadcast schedule, prediction-point sharding, the result gather
+and the not-positive-definite path of sif-xco2-cokriging_amd/distributed.py.  The panel
+arithmetic is the numpy stand-in of tests/fake_panel_handle.py (the HIP kernels need a GPU and
+are covered by the -m gpu tests, including the same driver at world = 1)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cokrige_oracle as orc
+from tests.conftest import load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sif_xco2_cokriging_amd.distributed import DistributedJoint
+        from tests.fake_panel_handle import FakePanelHandle
+        if case == "solve":
+            g = load_golden("joint_solve")
+            h = FakePanelHandle(g["params_A"], [g["coords0_A"], g["coords1_A"]], [g["values0_A"], g["values1_A"]], 0)
+            r = DistributedJoint(h, rank, world, dist_module=dist).prepare(len(g["pcoords_A"]))
+            pred, err = r.predict(1, g["pcoords_A"])
+            q.put((rank, "ok", pred, err))
+        else:
+            g = load_golden("joint_not_pd")
+            h = FakePanelHandle(g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], 0)
+            r = DistributedJoint(h, rank, world, dist_module=dist).prepare(5)
+            try:
+                r.predict(0, g["coords0"][:5])
+                q.put((rank, "no-raise", None, None))
+            except np.linalg.LinAlgError as e:
+                q.put((rank, str(e), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda t: t[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_joint_predict_two_ranks(world):
+    g = load_golden("joint_solve")
+    out = _run(world, "solve")
+    for rank, status, pred, err in out:
+        assert status == "ok"
+        assert np.max(np.abs(pred - g["pred_A_1"])) / np.max(np.abs(g["pred_A_1"])) < 1e-9
+        assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-10
+    # every rank returns the same full-length vectors
+    assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_not_positive_definite_all_ranks_raise():
+    g = load_golden("joint_not_pd")
+    out = _run(2, "npd")
+    for rank, status, _, _ in out:
+        assert status == str(g["message"]), status
+
+
+def test_single_rank_fake_matches_oracle():
+    """world = 1 through the same driver, no process group."""
+    from sif_xco2_cokriging_amd.distributed import DistributedJoint
+    from tests.fake_panel_handle import FakePanelHandle
+    g = load_golden("joint_solve")
+    h = FakePanelHandle(g["params_R"], [g["coords0_R"], g["coords1_R"]], [g["values0_R"], g["values1_R"]], 0)
+    pred, err = DistributedJoint(h, 0, 1).prepare(120).predict(0, g["pcoords_R"])
+    assert np.max(np.abs(pred - g["pred_R_0"])) / np.max(np.abs(g["pred_R_0"])) < 1e-9

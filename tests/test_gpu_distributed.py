@@ -1,0 +1,114 @@
+"""The multi-rank HIP code path on ONE GPU: two processes share cuda:0, each with its own
+handle partitioned (rank, world = 2) -- block-column-cyclic ownership, receive buffers, the
+strided trailing-update launch -- with the panel exchange done over gloo (RCCL refuses two
+ranks on one device; the driver's 8-GPU run uses the nccl backend through the same code)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class _GlooViaHost:
+    """torch.distributed facade that stages device tensors through the host for gloo."""
+
+    def __init__(self, dist):
+        self.d = dist
+
+    def broadcast(self, t, src, group=None):
+        c = t.cpu()
+        self.d.broadcast(c, src=src)
+        t.copy_(c)
+
+    def all_gather(self, outs, t, group=None):
+        cs = [o.cpu() for o in outs]
+        self.d.all_gather(cs, t.cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sif_xco2_cokriging_amd import native
+        from sif_xco2_cokriging_amd.distributed import DistributedJoint
+        g = load_golden("joint_solve")
+        # enlarge the problem beyond one 512-panel per rank: 3 panels
+        rng = np.random.default_rng(11)
+        lat = rng.uniform(25, 50, 1300)
+        lon = rng.uniform(-120, -70, 1300)
+        pts = np.column_stack([lat, lon])
+        coords = [pts[:700], pts[500:1300]]
+        values = [rng.standard_normal(700), rng.standard_normal(800)]
+        pv = g["params_A"]
+        h = native.Handle(0)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(0)
+        for k in range(2):
+            h.set_data(k, coords[k], values[k])
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        r = DistributedJoint(h, rank, world, dist_module=_GlooViaHost(dist), device=dev).prepare(len(g["pcoords_A"]))
+        pred, err = r.predict(0, g["pcoords_A"])
+        q.put((rank, pred, err, coords, values))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_matches_oracle():
+    import torch.multiprocessing as mp
+    from oracle import cokrige_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("joint_solve")
+    _, pred0, err0, coords, values = out[0]
+    p = orc.Params.from_flat(g["params_A"])
+    rp, re = orc.joint_predict(p, coords, values, g["pcoords_A"], 0, 0)
+    assert np.max(np.abs(pred0 - rp)) / np.max(np.abs(rp)) < 1e-9
+    assert np.max(np.abs(err0 ** 2 - re ** 2)) < 1e-10
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_world1_driver_with_arena_matches_direct():
+    """the same driver at world = 1 with a torch-owned arena == ck_factor + ck_predict."""
+    import torch
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.distributed import DistributedJoint
+    g = load_golden("joint_solve")
+    pv = g["params_R"]
+
+    def mk():
+        h = native.Handle(0)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(0)
+        h.set_data(0, g["coords0_R"], g["values0_R"])
+        h.set_data(1, g["coords1_R"], g["values1_R"])
+        return h
+    h1 = mk()
+    r = DistributedJoint(h1, 0, 1, device=torch.device("cuda", 0)).prepare(len(g["pcoords_R"]))
+    p1, e1 = r.predict(1, g["pcoords_R"])
+    h2 = mk()
+    h2.assemble_joint()
+    assert h2.factor() == 0
+    p2, e2 = h2.predict(1, g["pcoords_R"])
+    assert np.array_equal(p1, p2) and np.array_equal(e1, e2)
+    assert np.max(np.abs(p1 - g["pred_R_1"])) / np.max(np.abs(g["pred_R_1"])) < 1e-9

@@ -1,0 +1,89 @@
+"""The device math header (csrc/ck_math.h) compiled for the host (tests/host_math_shim.cpp, g++):
+K_nu / Matern correlation / haversine against mpmath, scipy and the oracle, without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.special as sps
+
+from oracle import cokrige_oracle as orc
+from tests.conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(ROOT, "tests", "_build", "libck_host_math.so")
+    csrc = os.path.join(ROOT, "sif-xco2-cokriging_amd", "csrc")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-I" + csrc, os.path.join(ROOT, "tests", "host_math_shim.cpp"),
+                    os.path.join(csrc, "ck_model.cpp"), "-o", so], check=True)
+    return ctypes.CDLL(so)
+
+
+def _rho(shim, nu, s):
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    out = np.empty_like(s)
+    shim.shim_rho_scaled(ctypes.c_double(nu), s.ctypes.data_as(dp), ctypes.c_long(s.size), out.ctypes.data_as(dp))
+    return out
+
+
+def _kv(shim, nu, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    shim.shim_kv(ctypes.c_double(nu), x.ctypes.data_as(dp), ctypes.c_long(x.size), out.ctypes.data_as(dp))
+    return out
+
+
+def test_temme_constants_vs_mpmath(shim):
+    import mpmath as mp
+    mp.mp.dps = 40
+    out = np.empty(8)
+    for nu in [0.2, 0.39, 0.4999, 0.51, 0.99, 0.9986, 1.0, 1.000001, 1.015, 1.3, 2.0, 2.2, 3.0, 3.4999, 3.499987]:
+        shim.shim_consts(ctypes.c_double(nu), out.ctypes.data_as(dp))
+        mu = mp.mpf(float(out[0]))
+        gp, gm = 1 / mp.gamma(1 + mu), 1 / mp.gamma(1 - mu)
+        g1 = (gm - gp) / (2 * mu) if mu != 0 else -mp.euler
+        g2 = (gm + gp) / 2
+        assert abs(out[1] / float(g1) - 1) < 4e-16, (nu, out[1], float(g1))
+        assert abs(out[2] / float(g2) - 1) < 4e-16
+        assert abs(out[3] / float(gp) - 1) < 4e-16 and abs(out[4] / float(gm) - 1) < 4e-16
+        assert float(out[7]) == float(int(np.floor(nu + 0.5)))
+
+
+def test_kv_vs_mpmath(shim):
+    import mpmath as mp
+    mp.mp.dps = 40
+    x = np.concatenate([np.logspace(-8, np.log10(2), 25), np.linspace(2.0001, 40, 25), [100.0, 400.0, 690.0]])
+    for nu in [0.2, 0.39, 0.695, 0.9986, 1.0, 1.3, 2.2, 3.0, 3.4999]:
+        ref = np.array([float(mp.besselk(nu, mp.mpf(float(t)))) for t in x])
+        assert np.max(np.abs(_kv(shim, nu, x) / ref - 1)) < 5e-15, nu
+
+
+def test_rho_vs_reference_grid(shim):
+    """against the reference's own _matern_correlation values (fixture); scipy's kv deviates
+    from mpmath by up to 1e-13 around x = 2, hence the 5e-13."""
+    g = load_golden("kv_grid")
+    for k, nu in enumerate(g["nus"]):
+        h = g["h"][1:]
+        r = _rho(shim, nu, np.sqrt(2 * nu) * h)
+        ref = g["rho"][k][1:]
+        big = ref > 1e-290
+        assert np.max(np.abs(r[big] / ref[big] - 1)) < 5e-13, nu
+
+
+def test_haversine_vs_oracle(shim):
+    g = load_golden("cov_blocks")
+    A, B = np.ascontiguousarray(g["A"]), np.ascontiguousarray(g["B"])
+    out = np.empty((len(A), len(B)))
+    shim.shim_haversine(A.ctypes.data_as(dp), ctypes.c_long(len(A)), B.ctypes.data_as(dp), ctypes.c_long(len(B)),
+                        out.ctypes.data_as(dp))
+    assert np.max(np.abs(out - g["hav_AB"])) / np.max(g["hav_AB"]) < 1e-14
+    out2 = np.empty((len(A), len(A)))
+    shim.shim_haversine(A.ctypes.data_as(dp), ctypes.c_long(len(A)), A.ctypes.data_as(dp), ctypes.c_long(len(A)),
+                        out2.ctypes.data_as(dp))
+    assert np.array_equal(out2 == 0, g["hav_AA"] == 0)
