@@ -51,9 +51,10 @@ int ck_device_count(int* n);
 /* ---- handle ---------------------------------------------------------------- */
 int ck_create(int device_id, ck_handle** out);
 int ck_destroy(ck_handle* h);
-/* Use an external HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the handle's own stream. */
-int ck_set_stream(ck_handle* h, void* hip_stream);
+/* external != 0: launch on the caller's HIP stream (hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL is the legacy default stream, which is what
+ * torch uses unless told otherwise).  external == 0: back to the handle's own stream. */
+int ck_set_stream(ck_handle* h, void* hip_stream, int external);
 /* Let the caller provide all device storage (e.g. one torch uint8 tensor), so a
  * host framework owns the memory and can run collectives on slices of it.
  * Without an arena the library allocates with hipMalloc.  Must precede ck_set_data. */

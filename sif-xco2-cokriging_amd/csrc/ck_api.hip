@@ -173,9 +173,9 @@ extern "C" int ck_destroy(ck_handle* h) {
     return 0;
 }
 
-extern "C" int ck_set_stream(ck_handle* h, void* hip_stream) {
+extern "C" int ck_set_stream(ck_handle* h, void* hip_stream, int external) {
     CHKH(h);
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = external ? (hipStream_t)hip_stream : h->own_stream;
     return 0;
 }
 

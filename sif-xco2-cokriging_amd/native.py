@@ -28,7 +28,7 @@ _PROTOS = {
     "ck_device_count": [POINTER(c_int)],
     "ck_create": [c_int, POINTER(c_void_p)],
     "ck_destroy": [c_void_p],
-    "ck_set_stream": [c_void_p, c_void_p],
+    "ck_set_stream": [c_void_p, c_void_p, c_int],
     "ck_set_arena": [c_void_p, c_void_p, c_int64],
     "ck_synchronize": [c_void_p],
     "ck_estimate_bytes": [c_void_p, c_int64, POINTER(c_int64)],
@@ -155,8 +155,10 @@ class Handle:
             pass
 
     # -- configuration ------------------------------------------------------------------
-    def set_stream(self, stream_ptr):
-        _chk(lib().ck_set_stream(self._h, c_void_p(stream_ptr or 0)))
+    def set_stream(self, stream_ptr, external=True):
+        """Launch on the caller's HIP stream (0 = the legacy default stream torch uses);
+        ``external=False`` restores the handle's own stream."""
+        _chk(lib().ck_set_stream(self._h, c_void_p(stream_ptr or 0), int(bool(external))))
 
     def set_arena(self, dev_ptr: int, nbytes: int, keepalive=None):
         self._keep.append(keepalive)

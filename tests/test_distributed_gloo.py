@@ -57,7 +57,15 @@ def _run(world, case):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=180) for _ in range(world)]
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+            assert time.time() - t0 < 180, "timeout"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -75,7 +75,16 @@ def test_two_ranks_one_gpu_matches_oracle():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < 2:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+            assert time.time() - t0 < 240, "timeout"
+    out.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
