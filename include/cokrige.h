@@ -151,7 +151,14 @@ int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
  * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin). */
 int ck_timings(ck_handle* h, double* out, int n);
-/* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events. */
+/* The assembly kernels evaluate the Matern correlation through a per-block table of log rho
+ * over the squared chord (built on the device from the exact K_nu evaluator and verified against
+ * it when the data are laid out).  Per block (0 = 11, 1 = 12, 2 = 22): whether the table passed
+ * its check (else that block uses the exact evaluator), its size / range, its measured error. */
+int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, double* q_lo, double* q_hi,
+                  double* max_rel_err);
+/* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events;
+ * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables. */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);
 /* Plain C -= A B^T on device buffers through the MFMA kernel (tests / microbenchmarks).
  * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), all row-major device doubles;

@@ -67,6 +67,15 @@ struct ck_handle {
     int nK = 0;
     bool layout_ready = false;
     double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *z = nullptr;   // stacked sites / values (Npad)
+    double* su = nullptr;               // chord vectors of the stacked sites (3 x Npad)
+    double* pu = nullptr;               // chord vectors of the prediction sites (3 x mpad)
+    // tabulated correlation (fast assembly)
+    CkTable tab[3];
+    double* d_coef[3] = {nullptr, nullptr, nullptr};
+    CkTable* d_tabs = nullptr;
+    double** d_coefptr = nullptr;
+    bool tables_built = false;
+    bool exact_cov = false;             // option "exact_cov": bypass the tables
     std::vector<double*> sig;    // per panel; nullptr if not owned
     double** d_sigptr = nullptr;
     double* recv[2] = {nullptr, nullptr};   // receive buffers for remote panels (world > 1)
@@ -162,6 +171,10 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (void* p : h->owned) (void)hipFree(p);
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_info);
+    if (h->d_tabs) (void)hipFree(h->d_tabs);
+    if (h->d_coefptr) (void)hipFree(h->d_coefptr);
+    for (int b = 0; b < 3; ++b)
+        if (h->d_coef[b]) (void)hipFree(h->d_coef[b]);
     for (auto& e : h->gemm_ev) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -249,6 +262,77 @@ extern "C" int ck_set_data(ck_handle* h, int k, const double* coords, const doub
 
 static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// ---------------------------------------------------------------------------------------
+// tabulated correlation: build log rho(q) tables for every Matern block of the model
+// (ck_math.h "Tabulated correlation").  Node values come from the exact device evaluator;
+// the degree-10 Chebyshev fit per interval is done here in long double; the result is
+// checked on the device against the exact evaluator and disabled if it misses 2e-13.
+// ---------------------------------------------------------------------------------------
+static int build_tables(ck_handle* h, double qbox_euclid) {
+    const int nblk = h->n_procs == 1 ? 1 : 3;
+    const int ND = CK_TAB_DEG + 1;
+    if (!h->d_tabs) {
+        HIPCHK(hipMalloc((void**)&h->d_tabs, 3 * sizeof(CkTable)));
+        HIPCHK(hipMalloc((void**)&h->d_coefptr, 3 * sizeof(double*)));
+        for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void**)&h->d_coef[b], (size_t)ND * CK_TAB_MAXINT * 8));
+    }
+    unsigned long long* d_err = nullptr;
+    double *d_q = nullptr, *d_f = nullptr;
+    HIPCHK(hipMalloc((void**)&d_err, 8));
+    HIPCHK(hipMalloc((void**)&d_q, (size_t)ND * CK_TAB_MAXINT * 8));
+    HIPCHK(hipMalloc((void**)&d_f, (size_t)ND * CK_TAB_MAXINT * 8));
+    std::vector<double> hq(ND * CK_TAB_MAXINT), hf(ND * CK_TAB_MAXINT), hcoef(ND * CK_TAB_MAXINT);
+    for (int b = 0; b < 3; ++b) {
+        CkTable& T = h->tab[b];
+        memset(&T, 0, sizeof(T));
+        if (b >= nblk) {
+            T = h->tab[0];
+            continue;
+        }
+        const CkMatern& m = h->blk[b];
+        int64_t base = 0;
+        int n_int = ck_table_plan(&m, h->metric, qbox_euclid, &base, hq.data());
+        if (n_int <= 0) continue;
+        HIPCHK(hipMemcpyAsync(d_q, hq.data(), (size_t)n_int * ND * 8, hipMemcpyHostToDevice, h->stream));
+        ck_launch_table_nodes(h->stream, h->d_blk + b, h->metric, d_q, (int64_t)n_int * ND, d_f);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hf.data(), d_f, (size_t)n_int * ND * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        // drop the far tail where rho has underflowed (log rho = -inf): the exact path returns 0 there
+        int n_ok = n_int;
+        for (int it = 0; it < n_int && n_ok == n_int; ++it)
+            for (int j = 0; j < ND; ++j)
+                if (!(fabs(hf[it * ND + j]) < 1e300)) {
+                    n_ok = it;
+                    break;
+                }
+        n_int = n_ok;
+        if (n_int <= 0) continue;
+        ck_table_fit(hf.data(), n_int, hcoef.data());
+        HIPCHK(hipMemcpyAsync(h->d_coef[b], hcoef.data(), (size_t)ND * n_int * 8, hipMemcpyHostToDevice, h->stream));
+        T.base = (int32_t)base;
+        T.n_int = n_int;
+        T.q_lo = ck_table_edge(base);
+        T.q_hi = ck_table_edge(base + n_int);
+        HIPCHK(hipMemsetAsync(d_err, 0, 8, h->stream));
+        ck_launch_table_check(h->stream, h->d_blk + b, h->metric, T, h->d_coef[b], d_err);
+        HIPCHK(hipGetLastError());
+        unsigned long long eb = 0;
+        HIPCHK(hipMemcpyAsync(&eb, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(&T.max_rel_err, &eb, 8);
+        T.enabled = (T.max_rel_err < 2e-13) ? 1 : 0;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_tabs, h->tab, 3 * sizeof(CkTable), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_coefptr, h->d_coef, 3 * sizeof(double*), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_err);
+    (void)hipFree(d_q);
+    (void)hipFree(d_f);
+    h->tables_built = true;
+    return 0;
+}
+
 // Decide the padded layout, upload sites / values, allocate the owned panels.
 static int ensure_layout(ck_handle* h) {
     if (h->layout_ready) return 0;
@@ -262,9 +346,11 @@ static int ensure_layout(ck_handle* h) {
     h->nK = (int)(h->Npad / CK_NB);
     const int64_t Np = h->Npad;
     if (!h->s0) {
-        if (dev_alloc(h, (void**)&h->s0, Np * 8) || dev_alloc(h, (void**)&h->s1, Np * 8) ||
-            dev_alloc(h, (void**)&h->s2, Np * 8) || dev_alloc(h, (void**)&h->z, Np * 8))
+        if (dev_alloc(h, (void**)&h->s0, 3 * Np * 8) || dev_alloc(h, (void**)&h->su, 3 * Np * 8) ||
+            dev_alloc(h, (void**)&h->z, Np * 8))
             return -1;
+        h->s1 = h->s0 + Np;
+        h->s2 = h->s0 + 2 * Np;
     }
     // stage coords -> device, transform
     std::vector<double> hc(2 * Np, 0.0), hz(Np, 0.0);
@@ -278,9 +364,22 @@ static int ensure_layout(ck_handle* h) {
     HIPCHK(hipMalloc((void**)&d_tmp, 2 * Np * 8));
     HIPCHK(hipMemcpyAsync(d_tmp, hc.data(), 2 * Np * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->z, hz.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
-    ck_launch_prep_sites(h->stream, d_tmp, Np, h->metric, h->s0, h->s1, h->s2);
+    ck_launch_prep_sites(h->stream, d_tmp, Np, h->metric, h->s0, h->s1, h->s2, h->su);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d_tmp));
+    // squared bounding-box diagonal of the data sites (Euclidean table range)
+    double qbox = 0.0;
+    {
+        double lo0 = 1e300, hi0 = -1e300, lo1 = 1e300, hi1 = -1e300;
+        for (int64_t k = 0; k < h->N; ++k) {
+            lo0 = fmin(lo0, hc[2 * k]);
+            hi0 = fmax(hi0, hc[2 * k]);
+            lo1 = fmin(lo1, hc[2 * k + 1]);
+            hi1 = fmax(hi1, hc[2 * k + 1]);
+        }
+        qbox = (hi0 - lo0) * (hi0 - lo0) + (hi1 - lo1) * (hi1 - lo1);
+    }
+    if (build_tables(h, qbox)) return -1;
     // panels
     if (h->sig.empty()) {
         h->sig.assign(h->nK, nullptr);
@@ -320,8 +419,8 @@ static int dense_common(ck_handle* h, int bidx, int add_nugget, int mode, const 
     HIPCHK(hipMalloc((void**)&dO, a * b * 8));
     HIPCHK(hipMemcpyAsync(dA, A, 2 * a * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dB, B, 2 * b * 8, hipMemcpyHostToDevice, h->stream));
-    ck_launch_prep_sites(h->stream, dA, a, h->metric, ta, ta + a, ta + 2 * a);
-    ck_launch_prep_sites(h->stream, dB, b, h->metric, tb, tb + b, tb + 2 * b);
+    ck_launch_prep_sites(h->stream, dA, a, h->metric, ta, ta + a, ta + 2 * a, nullptr);
+    ck_launch_prep_sites(h->stream, dB, b, h->metric, tb, tb + b, tb + 2 * b, nullptr);
     ck_launch_cov_dense(h->stream, h->d_blk + bidx, h->metric, add_nugget, mode, ta, ta + a, ta + 2 * a, a, tb, tb + b,
                         tb + 2 * b, b, dO);
     HIPCHK(hipGetLastError());
@@ -375,8 +474,13 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int K = h->rank; K < h->nK; K += h->world) {
         const int64_t row0 = (int64_t)K * CK_NB;
-        ck_launch_assemble_sigma_panel(h->stream, h->d_blk, h->metric, h->s0, h->s1, h->s2, h->n[0], h->N, row0,
-                                       h->Npad - row0, row0, h->sig[K]);
+        if (h->exact_cov)
+            ck_launch_assemble_sigma_panel(h->stream, h->d_blk, h->metric, h->s0, h->s1, h->s2, h->n[0], h->N, row0,
+                                           h->Npad - row0, row0, h->sig[K]);
+        else
+            ck_launch_assemble_sigma_panel_fast(h->stream, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0,
+                                                h->su, h->Npad, h->n[0], h->N, row0, h->Npad - row0, row0,
+                                                h->sig[K]);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(long long), h->stream));
@@ -557,7 +661,9 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
         dev_free_one(h, h->p0);
         dev_free_one(h, h->d_pcoords);
         dev_free_one(h, h->d_pred);
+        dev_free_one(h, h->pu);
         if (dev_alloc(h, (void**)&h->p0, 3 * mpad * 8)) return -1;
+        if (dev_alloc(h, (void**)&h->pu, 3 * mpad * 8)) return -1;
         if (dev_alloc(h, (void**)&h->d_pcoords, 2 * mpad * 8)) return -1;
         if (dev_alloc(h, (void**)&h->d_pred, 2 * mpad * 8)) return -1;
         h->p_cap = mpad;
@@ -571,11 +677,17 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
     if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
-    ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2);
-    for (int K = 0; K < h->nK; ++K)
-        ck_launch_assemble_aux_panel(h->stream, h->d_blk, h->metric, i, h->p0, h->p1, h->p2, m, mpad, h->s0, h->s1,
-                                     h->s2, h->z, h->n[0], h->N, (int64_t)K * CK_NB,
-                                     h->aux + (int64_t)K * mpad * CK_NB);
+    ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
+    for (int K = 0; K < h->nK; ++K) {
+        if (h->exact_cov)
+            ck_launch_assemble_aux_panel(h->stream, h->d_blk, h->metric, i, h->p0, h->p1, h->p2, m, mpad, h->s0,
+                                         h->s1, h->s2, h->z, h->n[0], h->N, (int64_t)K * CK_NB,
+                                         h->aux + (int64_t)K * mpad * CK_NB);
+        else
+            ck_launch_assemble_aux_panel_fast(h->stream, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i, h->p0,
+                                              h->pu, m, mpad, h->s0, h->su, h->Npad, h->z, h->n[0], h->N,
+                                              (int64_t)K * CK_NB, h->aux + (int64_t)K * mpad * CK_NB);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));   // pcoords is caller memory: do not return before the copy is done
@@ -837,12 +949,12 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     const int64_t Np = roundup(N, CK_NB);
     const int nK = (int)(Np / CK_NB);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
-    int64_t tot = 4 * al(Np * 8);
+    int64_t tot = 2 * al(3 * Np * 8) + al(Np * 8);
     for (int K = h->rank; K < nK; K += h->world) tot += al((Np - (int64_t)K * CK_NB) * CK_NB * 8);
     tot += al((int64_t)nK * sizeof(double*));
     if (h->world > 1) tot += 2 * al(Np * CK_NB * 8);
     const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
-    tot += al(mpad * Np * 8) + al(3 * mpad * 8) + 2 * al(2 * mpad * 8);
+    tot += al(mpad * Np * 8) + 2 * al(3 * mpad * 8) + 2 * al(2 * mpad * 8);
     *out = tot + 4096;
     return 0;
 }
@@ -854,7 +966,25 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->time_gemm = value != 0;
         return 0;
     }
+    if (!strcmp(name, "exact_cov")) {   // 1: per-entry Bessel evaluation instead of the tables
+        h->exact_cov = value != 0;
+        return 0;
+    }
     return fail(std::string("unknown option ") + name);
+}
+
+extern "C" int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, double* q_lo, double* q_hi,
+                             double* max_rel_err) {
+    CHKH(h);
+    if (block < 0 || block > 2) return fail("block must be 0 (11), 1 (12) or 2 (22)");
+    if (ensure_layout(h)) return -1;
+    const CkTable& T = h->tab[block];
+    if (enabled) *enabled = T.enabled;
+    if (n_intervals) *n_intervals = T.n_int;
+    if (q_lo) *q_lo = T.q_lo;
+    if (q_hi) *q_hi = T.q_hi;
+    if (max_rel_err) *max_rel_err = T.max_rel_err;
+    return 0;
 }
 
 extern "C" int ck_timings(ck_handle* h, double* out, int n) {

@@ -14,7 +14,21 @@
 // ---- covariance assembly (ck_cov.hip) ---------------------------------------
 // per-site transform: degrees -> (lat_rad, lon_rad, cos lat) | (x, y, 0)
 void ck_launch_prep_sites(hipStream_t s, const double* coords, int64_t n, int metric, double* c0, double* c1,
-                          double* c2);
+                          double* c2, double* u /* 3 x n chord vectors, may be null */);
+// tabulated fast path (ck_math.h "Tabulated correlation")
+void ck_launch_table_nodes(hipStream_t s, const CkMatern* m, int metric, const double* q, int64_t n, double* out);
+void ck_launch_table_check(hipStream_t s, const CkMatern* m, int metric, CkTable tab, const double* coef,
+                           unsigned long long* max_err_bits);
+// c: 3 x npad (exact coordinates), u: 3 x npad (chord vectors)
+void ck_launch_assemble_sigma_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
+                                         const double* const* coefs, int metric, const double* c, const double* u,
+                                         int64_t npad, int64_t n0, int64_t N, int64_t row0, int64_t nrows,
+                                         int64_t col0, double* out);
+void ck_launch_assemble_aux_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
+                                       const double* const* coefs, int metric, int i_pred, const double* pc,
+                                       const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
+                                       int64_t npad, const double* z, int64_t n0, int64_t N, int64_t col0,
+                                       double* out);
 // One block column of Sigma: rows [row0, row0 + nrows) x cols [col0, col0 + CK_NB), ld = CK_NB.
 // Sites are the stacked data sites (n0 of process 0, then N - n0 of process 1); entries with a
 // padded index (>= N) form an identity.

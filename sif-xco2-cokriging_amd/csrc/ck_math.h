@@ -214,6 +214,54 @@ CK_HD double ck_matern_rho_scaled(const CkMatern& m, double s) {
     return rho > 0.0 ? rho : 0.0;
 }
 
+// --------------------------------------------------------------------------
+// Tabulated correlation (fast assembly path)
+// --------------------------------------------------------------------------
+// For one Matern block, log rho is tabulated as a function of q, the SQUARED chord
+// (haversine: q = |u_i - u_j|^2 on the unit sphere, d = 2 R asin(sqrt(q)/2); Euclid: q = d^2).
+// q-space is cut at the double's exponent and top 3 mantissa bits (8 sub-intervals per octave),
+// so the interval index is one shift of the bit pattern; on every interval log rho is a
+// degree-10 polynomial in x in [-1, 1).  The nearest singularity of log rho(q) is q = 0, 23
+// half-widths away, so the Chebyshev interpolant converges like 46^-k: degree 10 is at the
+// rounding floor.  rho = exp(P(x)) costs 10 FMA + one exp instead of a Bessel evaluation plus
+// sqrt/asin/sin.  Coefficients are k-major (coef[k * n_int + interval]) so that lanes on
+// neighbouring intervals read neighbouring LDS banks.
+#define CK_TAB_DEG 10
+#define CK_TAB_SHIFT 49            /* bits >> 49 = exponent and top 3 mantissa bits */
+#define CK_TAB_MAXINT 320
+
+struct CkTable {
+    double q_lo, q_hi;     // table covers q_lo <= q < q_hi (interval aligned); outside: exact evaluator
+    int32_t base;          // (bits(q_lo) >> CK_TAB_SHIFT)
+    int32_t n_int;         // number of intervals
+    int32_t enabled;       // 0: use the exact evaluator for this block
+    int32_t pad_;
+    double max_rel_err;    // measured against the exact evaluator when the table was built
+};
+
+CK_HD double ck_table_x(double q, int* interval, int base) {
+    union { double d; uint64_t u; } v;
+    v.d = q;
+    *interval = (int)(v.u >> CK_TAB_SHIFT) - base;
+    v.u = ((v.u & ((1ULL << CK_TAB_SHIFT) - 1)) << 3) | 0x3FF0000000000000ULL;   // [1, 2)
+    return 2.0 * (v.d - 1.0) - 1.0;
+}
+
+CK_HD double ck_table_logrho(const double* coef, int n_int, int interval, double x) {
+    double p = coef[CK_TAB_DEG * n_int + interval];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = CK_TAB_DEG - 1; k >= 0; --k) p = p * x + coef[k * n_int + interval];
+    return p;
+}
+
+// scaled lag from the squared chord q
+CK_HD double ck_s_of_q(const CkMatern& m, int metric, double q) {
+    const double d = metric == CK_METRIC_HAVERSINE ? 2.0 * asin(0.5 * sqrt(q)) * CK_EARTH_RADIUS_KM : sqrt(q);
+    return m.sqrt2nu * (d / m.len_scale);
+}
+
 // covariance entry for lag h >= 0 (src/model.py:193-207)
 CK_HD double ck_cov_entry(const CkMatern& m, double h, int add_nugget) {
     if (h == 0.0) return add_nugget ? m.amp + m.nugget : m.amp;

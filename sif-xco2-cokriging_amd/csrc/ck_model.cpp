@@ -6,6 +6,7 @@
 #include "ck_model.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <string.h>
 
 // Taylor coefficients of 1/Gamma(z) = sum_{k>=1} c_k z^k  (Abramowitz & Stegun
@@ -112,4 +113,82 @@ extern "C" void ck_model_prepare(int n_procs, const double* sigma, const double*
     ck_matern_prepare(nu[0], len_scale[0], sigma[0] * sigma[0], nugget[0], &out3[0]);
     ck_matern_prepare(nu[1], len_scale[1], rho12 * (sigma[0] * sigma[1]), 0.0, &out3[1]);
     ck_matern_prepare(nu[2], len_scale[2], sigma[1] * sigma[1], nugget[1], &out3[2]);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// tabulated correlation: interval plan and per-interval Chebyshev fit (ck_math.h
+// "Tabulated correlation").  Host-side, long double; the node VALUES come from the device.
+// ---------------------------------------------------------------------------------------
+#define CK_ND (CK_TAB_DEG + 1)
+
+extern "C" double ck_table_edge(int64_t interval_index) {
+    const uint64_t u = (uint64_t)interval_index << CK_TAB_SHIFT;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+static long double cheb_node(int j) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    return cosl(PI * (j + 0.5L) / CK_ND);
+}
+
+// Decide the q-range of the table for one block and emit the Chebyshev nodes (n_int x 11 values
+// of q, interval-major).  Lower end: scaled lag 1/64 (closer pairs take the exact formulas);
+// upper end: q = 2 on the sphere (10 007 km) or 4x the squared bounding-box diagonal of the data.
+extern "C" int ck_table_plan(const CkMatern* m, int metric, double qbox_euclid, int64_t* base_out, double* q_nodes) {
+    const double d_lo = (1.0 / 64.0) * m->len_scale / m->sqrt2nu;
+    double q_lo_raw, q_hi;
+    if (metric == CK_METRIC_HAVERSINE) {
+        const double c = 2.0 * sin(0.5 * d_lo / CK_EARTH_RADIUS_KM);
+        q_lo_raw = c * c;
+        q_hi = 2.0;   // a quarter of the way round; beyond it (asin's branch point sits at q = 4) -> exact
+    } else {
+        q_lo_raw = d_lo * d_lo;
+        const double want = fmax(4.0 * qbox_euclid, 4.0 * q_lo_raw);
+        q_hi = 1.0;
+        while (q_hi < want) q_hi *= 2.0;
+        while (q_hi * 0.5 >= want) q_hi *= 0.5;
+    }
+    uint64_t ul, uh;
+    memcpy(&ul, &q_lo_raw, 8);
+    memcpy(&uh, &q_hi, 8);
+    int64_t base = (int64_t)(ul >> CK_TAB_SHIFT);
+    const int64_t top = (int64_t)(uh >> CK_TAB_SHIFT);
+    if (top - base > CK_TAB_MAXINT) base = top - CK_TAB_MAXINT;
+    const int n_int = (int)(top - base);
+    if (n_int <= 0) return 0;
+    for (int it = 0; it < n_int; ++it) {
+        const long double qa = ck_table_edge(base + it), qb = ck_table_edge(base + it + 1);
+        for (int j = 0; j < CK_ND; ++j)
+            q_nodes[it * CK_ND + j] = (double)(qa + (cheb_node(j) + 1.0L) * 0.5L * (qb - qa));
+    }
+    *base_out = base;
+    return n_int;
+}
+
+// node values f (n_int x 11, interval-major) -> monomial coefficients in x in [-1, 1), k-major
+extern "C" void ck_table_fit(const double* f, int n_int, double* coef_kmajor) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    long double Tm[CK_ND][CK_ND];   // Tm[k][i]: coefficient of x^i in the Chebyshev polynomial T_k
+    for (int k = 0; k < CK_ND; ++k)
+        for (int i = 0; i < CK_ND; ++i) Tm[k][i] = 0;
+    Tm[0][0] = 1;
+    Tm[1][1] = 1;
+    for (int k = 2; k < CK_ND; ++k)
+        for (int i = 0; i < CK_ND; ++i) Tm[k][i] = (i > 0 ? 2 * Tm[k - 1][i - 1] : 0) - Tm[k - 2][i];
+    for (int it = 0; it < n_int; ++it) {
+        long double ck[CK_ND];
+        for (int k = 0; k < CK_ND; ++k) {
+            long double acc = 0;
+            for (int j = 0; j < CK_ND; ++j) acc += (long double)f[it * CK_ND + j] * cosl(PI * k * (j + 0.5L) / CK_ND);
+            ck[k] = acc * (k == 0 ? 1.0L : 2.0L) / CK_ND;
+        }
+        for (int i = 0; i < CK_ND; ++i) {
+            long double a = 0;
+            for (int k = 0; k < CK_ND; ++k) a += ck[k] * Tm[k][i];
+            coef_kmajor[(size_t)i * n_int + it] = (double)a;
+        }
+    }
 }
