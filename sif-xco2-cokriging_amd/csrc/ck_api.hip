@@ -63,7 +63,8 @@ struct ck_handle {
     std::vector<double> h_coords[2], h_values[2];
     int64_t n[2] = {0, 0};
     bool data_set[2] = {false, false};
-    int64_t N = 0, Npad = 0;
+    int64_t N = 0, Npad = 0;      // N: observations; Npad: padded order of the internal matrix
+    int64_t n0p = 0, nend = 0;    // internal order: process 0 in [0, n0), process 1 in [n0p, nend)
     int nK = 0;
     bool layout_ready = false;
     double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *z = nullptr;   // stacked sites / values (Npad)
@@ -342,7 +343,10 @@ static int ensure_layout(ck_handle* h) {
     const int64_t n0 = h->n[0], n1 = h->n_procs == 2 ? h->n[1] : 0;
     h->N = n0 + n1;
     if (h->N <= 0) return fail("no observations");
-    h->Npad = roundup(h->N, CK_NB);
+    // process 1 starts on a 64-row tile boundary, so every assembly tile has ONE Matern block
+    h->n0p = n1 > 0 ? roundup(n0, 64) : n0;
+    h->nend = h->n0p + n1;
+    h->Npad = roundup(h->nend, CK_NB);
     h->nK = (int)(h->Npad / CK_NB);
     const int64_t Np = h->Npad;
     if (!h->s0) {
@@ -357,8 +361,8 @@ static int ensure_layout(ck_handle* h) {
     memcpy(hc.data(), h->h_coords[0].data(), 2 * n0 * 8);
     memcpy(hz.data(), h->h_values[0].data(), n0 * 8);
     if (n1) {
-        memcpy(hc.data() + 2 * n0, h->h_coords[1].data(), 2 * n1 * 8);
-        memcpy(hz.data() + n0, h->h_values[1].data(), n1 * 8);
+        memcpy(hc.data() + 2 * h->n0p, h->h_coords[1].data(), 2 * n1 * 8);
+        memcpy(hz.data() + h->n0p, h->h_values[1].data(), n1 * 8);
     }
     double* d_tmp = nullptr;
     HIPCHK(hipMalloc((void**)&d_tmp, 2 * Np * 8));
@@ -371,7 +375,8 @@ static int ensure_layout(ck_handle* h) {
     double qbox = 0.0;
     {
         double lo0 = 1e300, hi0 = -1e300, lo1 = 1e300, hi1 = -1e300;
-        for (int64_t k = 0; k < h->N; ++k) {
+        for (int64_t k = 0; k < h->nend; ++k) {
+            if (k >= n0 && k < h->n0p) continue;
             lo0 = fmin(lo0, hc[2 * k]);
             hi0 = fmax(hi0, hc[2 * k]);
             lo1 = fmin(lo1, hc[2 * k + 1]);
@@ -468,19 +473,25 @@ extern "C" int ck_cov_lags(ck_handle* h, int i, int j, const double* lags, int64
 // ---------------------------------------------------------------------------------------
 // joint path
 // ---------------------------------------------------------------------------------------
+static CkLayout layout_of(const ck_handle* h) { return CkLayout{h->n[0], h->n0p, h->nend, h->Npad}; }
+static bool tables_usable(const ck_handle* h) {
+    if (h->exact_cov) return false;
+    const int nblk = h->n_procs == 1 ? 1 : 3;
+    for (int b = 0; b < nblk; ++b)
+        if (!h->tab[b].enabled) return false;
+    return true;
+}
+// internal (padded-order) 1-based index -> index in the caller's stacked order
+static int64_t external_index(const ck_handle* h, int64_t g) { return g > h->n0p ? g - (h->n0p - h->n[0]) : g; }
+
 extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int K = h->rank; K < h->nK; K += h->world) {
         const int64_t row0 = (int64_t)K * CK_NB;
-        if (h->exact_cov)
-            ck_launch_assemble_sigma_panel(h->stream, h->d_blk, h->metric, h->s0, h->s1, h->s2, h->n[0], h->N, row0,
-                                           h->Npad - row0, row0, h->sig[K]);
-        else
-            ck_launch_assemble_sigma_panel_fast(h->stream, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0,
-                                                h->su, h->Npad, h->n[0], h->N, row0, h->Npad - row0, row0,
-                                                h->sig[K]);
+        ck_launch_assemble_sigma_panel(h->stream, tables_usable(h), h->d_blk, h->d_tabs, h->d_coefptr, h->metric,
+                                       h->s0, h->su, layout_of(h), row0, h->Npad - row0, row0, h->sig[K]);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(long long), h->stream));
@@ -618,8 +629,7 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    // a pivot inside the identity padding cannot fail; clamp defensively
-    *info = (int64_t)v;
+    *info = external_index(h, (int64_t)v);   // pivots inside the identity padding cannot fail
     return 0;
 }
 
@@ -678,16 +688,10 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
     HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
     if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
-    for (int K = 0; K < h->nK; ++K) {
-        if (h->exact_cov)
-            ck_launch_assemble_aux_panel(h->stream, h->d_blk, h->metric, i, h->p0, h->p1, h->p2, m, mpad, h->s0,
-                                         h->s1, h->s2, h->z, h->n[0], h->N, (int64_t)K * CK_NB,
-                                         h->aux + (int64_t)K * mpad * CK_NB);
-        else
-            ck_launch_assemble_aux_panel_fast(h->stream, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i, h->p0,
-                                              h->pu, m, mpad, h->s0, h->su, h->Npad, h->z, h->n[0], h->N,
-                                              (int64_t)K * CK_NB, h->aux + (int64_t)K * mpad * CK_NB);
-    }
+    for (int K = 0; K < h->nK; ++K)
+        ck_launch_assemble_aux_panel(h->stream, tables_usable(h), h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i,
+                                     h->p0, h->pu, m, mpad, h->s0, h->su, h->z, layout_of(h), (int64_t)K * CK_NB,
+                                     h->aux + (int64_t)K * mpad * CK_NB);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));   // pcoords is caller memory: do not return before the copy is done
@@ -910,6 +914,12 @@ extern "C" int ck_debug_get_lower(ck_handle* h, double* out, int64_t n) {
     if (n != h->N) return fail("n must equal the number of observations");
     std::vector<double> buf;
     memset(out, 0, (size_t)n * n * 8);
+    const int64_t gap = h->n0p - h->n[0];
+    auto ext = [&](int64_t g) -> int64_t {   // internal 0-based -> external 0-based, -1 for padding
+        if (g < h->n[0]) return g;
+        if (g >= h->n0p && g < h->nend) return g - gap;
+        return -1;
+    };
     for (int K = 0; K < h->nK; ++K) {
         if (!h->sig[K]) continue;
         const int64_t rows = h->Npad - (int64_t)K * CK_NB;
@@ -917,12 +927,14 @@ extern "C" int ck_debug_get_lower(ck_handle* h, double* out, int64_t n) {
         HIPCHK(hipMemcpyAsync(buf.data(), h->sig[K], rows * CK_NB * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (int64_t r = 0; r < rows; ++r) {
-            const int64_t gr = (int64_t)K * CK_NB + r;
-            if (gr >= n) break;
+            const int64_t er = ext((int64_t)K * CK_NB + r);
+            if (er < 0) continue;
             for (int64_t c = 0; c < CK_NB; ++c) {
                 const int64_t gc = (int64_t)K * CK_NB + c;
-                if (gc >= n || gc > gr) break;
-                out[gr * n + gc] = buf[r * CK_NB + c];
+                if (gc > (int64_t)K * CK_NB + r) break;
+                const int64_t ec = ext(gc);
+                if (ec < 0) continue;
+                out[er * n + ec] = buf[r * CK_NB + c];
             }
         }
     }
@@ -945,8 +957,8 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     CHKH(h);
     for (int k = 0; k < h->n_procs; ++k)
         if (!h->data_set[k]) return fail("ck_set_data missing for process " + std::to_string(k));
-    const int64_t N = h->n[0] + (h->n_procs == 2 ? h->n[1] : 0);
-    const int64_t Np = roundup(N, CK_NB);
+    const int64_t n1 = h->n_procs == 2 ? h->n[1] : 0;
+    const int64_t Np = roundup((n1 > 0 ? roundup(h->n[0], 64) : h->n[0]) + n1, CK_NB);
     const int nK = (int)(Np / CK_NB);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     int64_t tot = 2 * al(3 * Np * 8) + al(Np * 8);
@@ -984,6 +996,15 @@ extern "C" int ck_table_info(ck_handle* h, int block, int* enabled, int* n_inter
     if (q_lo) *q_lo = T.q_lo;
     if (q_hi) *q_hi = T.q_hi;
     if (max_rel_err) *max_rel_err = T.max_rel_err;
+    return 0;
+}
+
+extern "C" int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count) {
+    CHKH(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long v = 0;
+    if (ck_fallback_counter(h->stream, reset, &v)) return fail("cannot read the fallback counter");
+    if (count) *count = (int64_t)v;
     return 0;
 }
 

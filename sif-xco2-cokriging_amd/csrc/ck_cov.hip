@@ -53,55 +53,143 @@ __device__ __forceinline__ double pair_dist(int metric, double a0, double a1, do
     return metric == CK_METRIC_HAVERSINE ? ck_haversine_km(a0, a1, a2, b0, b1, b2) : ck_euclid(a0, a1, b0, b1);
 }
 
-// Sigma block column ---------------------------------------------------------------------
-// grid: (CK_NB / 64, nrows / 64); block 256 threads; tile 64 x 64.
-// thread (ty = t >> 4, tx = t & 15) computes rows ty + 16 a (a = 0..3), cols 2 tx + {0, 1} + 32 b (b = 0, 1):
-// every store instruction of a wave writes 4 rows x 256 contiguous bytes.
-__global__ __launch_bounds__(256) void k_assemble_sigma(const CkMatern* __restrict__ blk, int metric,
-                                                         const double* __restrict__ s0,
-                                                         const double* __restrict__ s1,
-                                                         const double* __restrict__ s2, long n0, long N, long row0,
-                                                         long col0, double* __restrict__ out) {
+// =========================================================================================
+// Assembly of Sigma block columns and of the right-hand-side rows
+// =========================================================================================
+// Internal site order (CkLayout): process 0 occupies [0, n0), padded to n0p = roundup(n0, 64);
+// process 1 occupies [n0p, nend); everything else up to npad is padding.  Because n0p is a
+// multiple of the 64 x 64 tile, every tile belongs to exactly ONE Matern block (11, 12 or 22):
+// no tile ever needs a per-entry block choice.  Entries that involve a padding index form an
+// identity (Sigma) or are zero (right-hand sides), so the factorisation of the padded matrix is
+// the factorisation of the real one.
+//
+// grid (CK_NB / 256, rows / 64), 256 threads; a workgroup walks four 64 x 64 sub-tiles.
+// thread (ty = t >> 4, tx = t & 15) computes rows ty + 16 a (a = 0..3), cols 2 tx + {0, 1} + 32 b
+// (b = 0, 1): every store instruction of a wave writes 4 rows x 256 contiguous bytes.
+struct CkSiteRef {   // SoA views of one site set
+    const double *c0, *c1, *c2;   // exact-formula coordinates (lat_rad, lon_rad, cos lat | x, y, 0)
+    const double *u0, *u1, *u2;   // chord vectors (table path)
+};
+
+__device__ __forceinline__ bool site_valid(const CkLayout& L, long g) {
+    return g < L.n0 || (g >= L.n0p && g < L.nend);
+}
+
+// the exact formulas as an out-of-line call: rare in the table kernels (pairs closer than the
+// table's lower end or beyond its upper end), and out of line it does not inflate their code
+__device__ __noinline__ double exact_entry_call(const CkMatern* m, int metric, int nug, double ac0, double ac1,
+                                                double ac2, double bc0, double bc1, double bc2) {
+    return ck_cov_entry(*m, pair_dist(metric, ac0, ac1, ac2, bc0, bc1, bc2), nug);
+}
+
+// number of entries the table path handed to the exact formulas since the last reset (diagnostic)
+__device__ unsigned long long g_ck_fallback_entries = 0;
+
+// One entry through the table.  The exact-formula call sits behind a WAVE-UNIFORM test (ballot):
+// hipcc does not reliably skip a short divergent block that holds a call.
+__device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, int metric,
+                                             int nug, double ac0, double ac1, double ac2, double au0, double au1,
+                                             double au2, double bc0, double bc1, double bc2, double bu0, double bu1,
+                                             double bu2) {
+    const bool same = (ac0 == bc0 && ac1 == bc1);   // h == 0 exactly (model.py:195-196)
+    const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
+    const double q = dx * dx + dy * dy + dz * dz;
+    const bool in_tab = (q >= tab.q_lo && q < tab.q_hi);
+    int iv;
+    const double x = ck_table_x(in_tab ? q : tab.q_lo, &iv, tab.base);   // keep the lookup in range
+    double val = m.amp * exp(ck_table_logrho(lcoef, tab.n_int, iv, x));
+    if (same) val = nug ? m.amp + m.nugget : m.amp;
+    const bool slow = !same && !in_tab;
+    const unsigned long long sl = __builtin_amdgcn_ballot_w64(slow);
+    if (sl != 0ULL) {
+        if (slow) val = exact_entry_call(&m, metric, nug, ac0, ac1, ac2, bc0, bc1, bc2);
+        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(sl))
+            atomicAdd(&g_ck_fallback_entries, (unsigned long long)__builtin_popcountll(sl));
+    }
+    return val;
+}
+
+// FAST: table path (every block's table enabled) | exact per-entry Bessel evaluation.
+// AUX:  rows are prediction sites (row m = data values z, rows > m zero) | rows are data sites.
+template <bool FAST, bool AUX>
+__global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ blk, const CkTable* __restrict__ tabs,
+                                                   const double* const* __restrict__ coefs, int metric, int i_pred,
+                                                   CkSiteRef R, long m, CkSiteRef S, const double* __restrict__ z,
+                                                   CkLayout L, long row0, long col0, double* __restrict__ out) {
+    __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_MAXINT : 1];
+    __shared__ CkTable ltab;
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    const long rt = row0 + (long)blockIdx.y * 64, ct = col0 + (long)blockIdx.x * 64;
-    // (a block column starts at its diagonal 512-block, which is written in full; everything
-    //  below it is in the lower triangle)
-    // uniform Matern block for the whole tile?
-    const int prA = rt >= n0, prB = (rt + 63) >= n0, pcA = ct >= n0, pcB = (ct + 63) >= n0;
-    const bool uni = (prA == prB) && (pcA == pcB) && (rt + 63 < N) && (ct + 63 < N);
-    double* obase = out + (rt - row0) * CK_NB + (ct - col0);
-    if (uni) {
-        const CkMatern& m = blk[prA + pcA];
-        const int nug = (prA == pcA);
+    const long rt = row0 + (long)blockIdx.y * 64;
+    const int pr = AUX ? i_pred : (int)(rt >= L.n0p);
+    // this thread's four rows
+    double rc0[4], rc1[4], rc2[4], ru0[4], ru1[4], ru2[4];
+    bool rv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long r = rt + ty + 16 * a;
+        rv[a] = AUX ? (r < m) : site_valid(L, r);
+        rc0[a] = R.c0[r];
+        rc1[a] = R.c1[r];
+        rc2[a] = R.c2[r];
+        if (FAST) {
+            ru0[a] = R.u0[r];
+            ru1[a] = R.u1[r];
+            ru2[a] = R.u2[r];
+        }
+    }
+    int loaded = -1;
+    for (int sub = 0; sub < 4; ++sub) {
+        const long ct = col0 + (long)blockIdx.x * 256 + sub * 64;
+        const int pc = (int)(ct >= L.n0p);
+        const int bidx = pr + pc;
+        const int nug = (pr == pc);
+        const CkMatern& mb = blk[bidx];
+        double* obase = out + (rt - row0) * CK_NB + (ct - col0);
+        if (FAST && loaded != bidx) {
+            __syncthreads();
+            if (t == 0) ltab = tabs[bidx];
+            const int cnt = (CK_TAB_DEG + 1) * tabs[bidx].n_int;
+            const double* src = coefs[bidx];
+            for (int k = t; k < cnt; k += 256) lcoef[k] = src[k];
+            __syncthreads();
+            loaded = bidx;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const long c = ct + 2 * tx + 32 * b;
-            const double b00 = s0[c], b01 = s1[c], b02 = s2[c];
-            const double b10 = s0[c + 1], b11 = s1[c + 1], b12 = s2[c + 1];
+            double cc0[2], cc1[2], cc2[2], cu0[2], cu1[2], cu2[2];
+            bool cv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cv[e] = site_valid(L, c + e);
+                cc0[e] = S.c0[c + e];
+                cc1[e] = S.c1[c + e];
+                cc2[e] = S.c2[c + e];
+                if (FAST) {
+                    cu0[e] = S.u0[c + e];
+                    cu1[e] = S.u1[c + e];
+                    cu2[e] = S.u2[c + e];
+                }
+            }
+            const double zc[2] = {AUX ? z[c] : 0.0, AUX ? z[c + 1] : 0.0};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const long r = rt + ty + 16 * a;
-                const double a0 = s0[r], a1 = s1[r], a2 = s2[r];
                 d2_t v;
-                v[0] = ck_cov_entry(m, pair_dist(metric, a0, a1, a2, b00, b01, b02), nug);
-                v[1] = ck_cov_entry(m, pair_dist(metric, a0, a1, a2, b10, b11, b12), nug);
-                *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-            }
-        }
-    } else {
-        for (int b = 0; b < 2; ++b) {
-            for (int a = 0; a < 4; ++a) {
-                const long r = rt + ty + 16 * a;
-                d2_t v;
+#pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const long c = ct + 2 * tx + 32 * b + e;
                     double val;
-                    if (r >= N || c >= N) {
-                        val = (r == c) ? 1.0 : 0.0;   // padding: identity
+                    if (FAST)
+                        val = fast_entry(mb, ltab, lcoef, metric, nug, rc0[a], rc1[a], rc2[a], ru0[a], ru1[a], ru2[a],
+                                         cc0[e], cc1[e], cc2[e], cu0[e], cu1[e], cu2[e]);
+                    else
+                        val = ck_cov_entry(mb, pair_dist(metric, rc0[a], rc1[a], rc2[a], cc0[e], cc1[e], cc2[e]), nug);
+                    if (AUX) {
+                        // rows: prediction sites | z | zero padding; padded columns are zero
+                        if (!rv[a]) val = (r == m) ? zc[e] : 0.0;
+                        if (!cv[e]) val = 0.0;
                     } else {
-                        const int pr = r >= n0, pc = c >= n0;
-                        val = ck_cov_entry(blk[pr + pc], pair_dist(metric, s0[r], s1[r], s2[r], s0[c], s1[c], s2[c]),
-                                           pr == pc);
+                        if (!(rv[a] && cv[e])) val = (r == c + e) ? 1.0 : 0.0;   // padding: identity
                     }
                     v[e] = val;
                 }
@@ -111,80 +199,36 @@ __global__ __launch_bounds__(256) void k_assemble_sigma(const CkMatern* __restri
     }
 }
 
-void ck_launch_assemble_sigma_panel(hipStream_t s, const CkMatern* blk, int metric, const double* s0,
-                                    const double* s1, const double* s2, int64_t n0, int64_t N, int64_t row0,
-                                    int64_t nrows, int64_t col0, double* out) {
+void ck_launch_assemble_sigma_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                                    const double* const* coefs, int metric, const double* c, const double* u,
+                                    CkLayout L, int64_t row0, int64_t nrows, int64_t col0, double* out) {
     if (nrows <= 0) return;
-    k_assemble_sigma<<<dim3(CK_NB / 64, (unsigned)(nrows / 64)), dim3(256), 0, s>>>(blk, metric, s0, s1, s2, n0, N,
-                                                                                    row0, col0, out);
+    const int64_t np = L.npad;
+    CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
+    dim3 grid(CK_NB / 256, (unsigned)(nrows / 64));
+    if (fast)
+        k_assemble<true, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, row0,
+                                                           col0, out);
+    else
+        k_assemble<false, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, row0,
+                                                            col0, out);
 }
 
-// right-hand-side rows (c0^T and z^T) ----------------------------------------------------
-// rows p < m: cov(prediction site p, data site c): C_ii with nugget-at-zero when the data site
-// belongs to the predicted process, else C_12 (src/joint_prediction.py:114-121).
-// row m: data values z (src/joint_prediction.py:67).  rows > m and padded columns: 0.
-__global__ __launch_bounds__(256) void k_assemble_aux(const CkMatern* __restrict__ blk, int metric, int i_pred,
-                                                       const double* __restrict__ p0, const double* __restrict__ p1,
-                                                       const double* __restrict__ p2, long m,
-                                                       const double* __restrict__ s0, const double* __restrict__ s1,
-                                                       const double* __restrict__ s2, const double* __restrict__ z,
-                                                       long n0, long N, long col0, double* __restrict__ out) {
-    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    const long rt = (long)blockIdx.y * 64, ct = col0 + (long)blockIdx.x * 64;
-    double* obase = out + rt * CK_NB + (ct - col0);
-    const int pcA = ct >= n0, pcB = (ct + 63) >= n0;
-    const bool uni = (pcA == pcB) && (ct + 63 < N) && (rt + 63 < m);
-    if (uni) {
-        const int nug = (pcA == i_pred);
-        const CkMatern& mb = blk[i_pred + pcA];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const long c = ct + 2 * tx + 32 * b;
-            const double b00 = s0[c], b01 = s1[c], b02 = s2[c];
-            const double b10 = s0[c + 1], b11 = s1[c + 1], b12 = s2[c + 1];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const long r = rt + ty + 16 * a;
-                const double a0 = p0[r], a1 = p1[r], a2 = p2[r];
-                d2_t v;
-                v[0] = ck_cov_entry(mb, pair_dist(metric, a0, a1, a2, b00, b01, b02), nug);
-                v[1] = ck_cov_entry(mb, pair_dist(metric, a0, a1, a2, b10, b11, b12), nug);
-                *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-            }
-        }
-    } else {
-        for (int b = 0; b < 2; ++b) {
-            for (int a = 0; a < 4; ++a) {
-                const long r = rt + ty + 16 * a;
-                d2_t v;
-                for (int e = 0; e < 2; ++e) {
-                    const long c = ct + 2 * tx + 32 * b + e;
-                    double val = 0.0;
-                    if (c < N) {
-                        if (r < m) {
-                            const int pc = c >= n0;
-                            val = ck_cov_entry(blk[i_pred + pc],
-                                               pair_dist(metric, p0[r], p1[r], p2[r], s0[c], s1[c], s2[c]),
-                                               pc == i_pred);
-                        } else if (r == m) {
-                            val = z[c];
-                        }
-                    }
-                    v[e] = val;
-                }
-                *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-            }
-        }
-    }
-}
-
-void ck_launch_assemble_aux_panel(hipStream_t s, const CkMatern* blk, int metric, int i_pred, const double* p0,
-                                  const double* p1, const double* p2, int64_t m, int64_t mpad, const double* s0,
-                                  const double* s1, const double* s2, const double* z, int64_t n0, int64_t N,
-                                  int64_t col0, double* out) {
+void ck_launch_assemble_aux_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                                  const double* const* coefs, int metric, int i_pred, const double* pc,
+                                  const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
+                                  const double* z, CkLayout L, int64_t col0, double* out) {
     if (mpad <= 0) return;
-    k_assemble_aux<<<dim3(CK_NB / 64, (unsigned)(mpad / 64)), dim3(256), 0, s>>>(blk, metric, i_pred, p0, p1, p2, m,
-                                                                                 s0, s1, s2, z, n0, N, col0, out);
+    const int64_t np = L.npad;
+    CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, pu, pu + mpad, pu + 2 * mpad};
+    CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
+    dim3 grid(CK_NB / 256, (unsigned)(mpad / 64));
+    if (fast)
+        k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, 0, col0,
+                                                          out);
+    else
+        k_assemble<false, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, 0, col0,
+                                                           out);
 }
 
 // dense a x b block (element-wise parity surface) ------------------------------------------
@@ -269,204 +313,13 @@ void ck_launch_table_check(hipStream_t s, const CkMatern* m, int metric, CkTable
     k_table_check<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(m, metric, tab, coef, max_err_bits);
 }
 
-struct CkSiteRef {   // SoA views of one site set
-    const double *c0, *c1, *c2;   // exact-formula coordinates
-    const double *u0, *u1, *u2;   // chord vectors
-};
-
-// the exact formulas as an out-of-line call: rare (pairs closer than the table's lower end or
-// beyond its upper end), and keeping it out of line keeps the table path's register count low
-__device__ __noinline__ double exact_entry_call(const CkMatern* m, int metric, int nug, double ac0, double ac1,
-                                                double ac2, double bc0, double bc1, double bc2) {
-    return ck_cov_entry(*m, pair_dist(metric, ac0, ac1, ac2, bc0, bc1, bc2), nug);
-}
-
-// one entry through the table, falling back to the exact formulas outside its range
-__device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, int metric,
-                                             int nug, double ac0, double ac1, double ac2, double au0, double au1,
-                                             double au2, double bc0, double bc1, double bc2, double bu0, double bu1,
-                                             double bu2) {
-    if (ac0 == bc0 && ac1 == bc1) return nug ? m.amp + m.nugget : m.amp;   // h == 0 exactly (model.py:195-196)
-    const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
-    const double q = dx * dx + dy * dy + dz * dz;
-    if (q >= tab.q_lo && q < tab.q_hi) {
-        int iv;
-        const double x = ck_table_x(q, &iv, tab.base);
-        return m.amp * exp(ck_table_logrho(lcoef, tab.n_int, iv, x));
+int ck_fallback_counter(hipStream_t s, int reset, unsigned long long* out) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ck_fallback_entries), 8) != hipSuccess) return -1;
+    if (out) *out = v;
+    if (reset) {
+        v = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ck_fallback_entries), &v, 8) != hipSuccess) return -1;
     }
-    return exact_entry_call(&m, metric, nug, ac0, ac1, ac2, bc0, bc1, bc2);
-}
-
-// Sigma block column, table path.  grid (CK_NB / 256, nrows / 64); a workgroup walks four 64 x 64
-// sub-tiles so that the table (<= 28 KB, staged in LDS) is loaded once per 128 KB of output.
-__global__ __launch_bounds__(256) void k_assemble_sigma_fast(const CkMatern* __restrict__ blk,
-                                                              const CkTable* __restrict__ tabs,
-                                                              const double* const* __restrict__ coefs, int metric,
-                                                              CkSiteRef S, long n0, long N, long row0, long col0,
-                                                              double* __restrict__ out) {
-    __shared__ double lcoef[(CK_TAB_DEG + 1) * CK_TAB_MAXINT];
-    __shared__ CkTable ltab;
-    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    const long rt = row0 + (long)blockIdx.y * 64;
-    int loaded = -1;
-    for (int sub = 0; sub < 4; ++sub) {
-        const long ct = col0 + (long)blockIdx.x * 256 + sub * 64;
-        const int prA = rt >= n0, prB = (rt + 63) >= n0, pcA = ct >= n0, pcB = (ct + 63) >= n0;
-        const bool uni = (prA == prB) && (pcA == pcB) && (rt + 63 < N) && (ct + 63 < N);
-        const int bidx = prA + pcA;
-        double* obase = out + (rt - row0) * CK_NB + (ct - col0);
-        if (uni && tabs[bidx].enabled) {
-            if (loaded != bidx) {
-                __syncthreads();
-                if (t == 0) ltab = tabs[bidx];
-                const int cnt = (CK_TAB_DEG + 1) * tabs[bidx].n_int;
-                const double* src = coefs[bidx];
-                for (int k = t; k < cnt; k += 256) lcoef[k] = src[k];
-                __syncthreads();
-                loaded = bidx;
-            }
-            const CkMatern& m = blk[bidx];
-            const int nug = (prA == pcA);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const long c = ct + 2 * tx + 32 * b;
-                const double b0c0 = S.c0[c], b0c1 = S.c1[c], b0c2 = S.c2[c], b0u0 = S.u0[c], b0u1 = S.u1[c],
-                             b0u2 = S.u2[c];
-                const double b1c0 = S.c0[c + 1], b1c1 = S.c1[c + 1], b1c2 = S.c2[c + 1], b1u0 = S.u0[c + 1],
-                             b1u1 = S.u1[c + 1], b1u2 = S.u2[c + 1];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const long r = rt + ty + 16 * a;
-                    const double ac0 = S.c0[r], ac1 = S.c1[r], ac2 = S.c2[r], au0 = S.u0[r], au1 = S.u1[r],
-                                 au2 = S.u2[r];
-                    d2_t v;
-                    v[0] = fast_entry(m, ltab, lcoef, metric, nug, ac0, ac1, ac2, au0, au1, au2, b0c0, b0c1, b0c2,
-                                      b0u0, b0u1, b0u2);
-                    v[1] = fast_entry(m, ltab, lcoef, metric, nug, ac0, ac1, ac2, au0, au1, au2, b1c0, b1c1, b1c2,
-                                      b1u0, b1u1, b1u2);
-                    *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-                }
-            }
-        } else {
-            // block boundary / padding / table disabled: exact formulas, per-entry block choice
-            for (int b = 0; b < 2; ++b) {
-                for (int a = 0; a < 4; ++a) {
-                    const long r = rt + ty + 16 * a;
-                    d2_t v;
-                    for (int e = 0; e < 2; ++e) {
-                        const long c = ct + 2 * tx + 32 * b + e;
-                        double val;
-                        if (r >= N || c >= N) {
-                            val = (r == c) ? 1.0 : 0.0;
-                        } else {
-                            const int pr = r >= n0, pc = c >= n0;
-                            val = exact_entry_call(&blk[pr + pc], metric, pr == pc, S.c0[r], S.c1[r], S.c2[r], S.c0[c],
-                                                   S.c1[c], S.c2[c]);
-                        }
-                        v[e] = val;
-                    }
-                    *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-                }
-            }
-        }
-    }
-}
-
-void ck_launch_assemble_sigma_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
-                                         const double* const* coefs, int metric, const double* c, const double* u,
-                                         int64_t npad, int64_t n0, int64_t N, int64_t row0, int64_t nrows,
-                                         int64_t col0, double* out) {
-    if (nrows <= 0) return;
-    CkSiteRef S{c, c + npad, c + 2 * npad, u, u + npad, u + 2 * npad};
-    k_assemble_sigma_fast<<<dim3(CK_NB / 256, (unsigned)(nrows / 64)), dim3(256), 0, s>>>(blk, tabs, coefs, metric, S,
-                                                                                          n0, N, row0, col0, out);
-}
-
-// right-hand-side rows, table path (same structure; rows = prediction sites)
-__global__ __launch_bounds__(256) void k_assemble_aux_fast(const CkMatern* __restrict__ blk,
-                                                            const CkTable* __restrict__ tabs,
-                                                            const double* const* __restrict__ coefs, int metric,
-                                                            int i_pred, CkSiteRef P, long m, CkSiteRef S,
-                                                            const double* __restrict__ z, long n0, long N, long col0,
-                                                            double* __restrict__ out) {
-    __shared__ double lcoef[(CK_TAB_DEG + 1) * CK_TAB_MAXINT];
-    __shared__ CkTable ltab;
-    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    const long rt = (long)blockIdx.y * 64;
-    int loaded = -1;
-    for (int sub = 0; sub < 4; ++sub) {
-        const long ct = col0 + (long)blockIdx.x * 256 + sub * 64;
-        const int pcA = ct >= n0, pcB = (ct + 63) >= n0;
-        const bool uni = (pcA == pcB) && (ct + 63 < N) && (rt + 63 < m);
-        const int bidx = i_pred + pcA;
-        double* obase = out + rt * CK_NB + (ct - col0);
-        if (uni && tabs[bidx].enabled) {
-            if (loaded != bidx) {
-                __syncthreads();
-                if (t == 0) ltab = tabs[bidx];
-                const int cnt = (CK_TAB_DEG + 1) * tabs[bidx].n_int;
-                const double* src = coefs[bidx];
-                for (int k = t; k < cnt; k += 256) lcoef[k] = src[k];
-                __syncthreads();
-                loaded = bidx;
-            }
-            const CkMatern& mb = blk[bidx];
-            const int nug = (pcA == i_pred);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const long c = ct + 2 * tx + 32 * b;
-                const double b0c0 = S.c0[c], b0c1 = S.c1[c], b0c2 = S.c2[c], b0u0 = S.u0[c], b0u1 = S.u1[c],
-                             b0u2 = S.u2[c];
-                const double b1c0 = S.c0[c + 1], b1c1 = S.c1[c + 1], b1c2 = S.c2[c + 1], b1u0 = S.u0[c + 1],
-                             b1u1 = S.u1[c + 1], b1u2 = S.u2[c + 1];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const long r = rt + ty + 16 * a;
-                    const double ac0 = P.c0[r], ac1 = P.c1[r], ac2 = P.c2[r], au0 = P.u0[r], au1 = P.u1[r],
-                                 au2 = P.u2[r];
-                    d2_t v;
-                    v[0] = fast_entry(mb, ltab, lcoef, metric, nug, ac0, ac1, ac2, au0, au1, au2, b0c0, b0c1, b0c2,
-                                      b0u0, b0u1, b0u2);
-                    v[1] = fast_entry(mb, ltab, lcoef, metric, nug, ac0, ac1, ac2, au0, au1, au2, b1c0, b1c1, b1c2,
-                                      b1u0, b1u1, b1u2);
-                    *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-                }
-            }
-        } else {
-            for (int b = 0; b < 2; ++b) {
-                for (int a = 0; a < 4; ++a) {
-                    const long r = rt + ty + 16 * a;
-                    d2_t v;
-                    for (int e = 0; e < 2; ++e) {
-                        const long c = ct + 2 * tx + 32 * b + e;
-                        double val = 0.0;
-                        if (c < N) {
-                            if (r < m) {
-                                const int pc = c >= n0;
-                                val = exact_entry_call(&blk[i_pred + pc], metric, pc == i_pred, P.c0[r], P.c1[r], P.c2[r],
-                                                       S.c0[c], S.c1[c], S.c2[c]);
-                            } else if (r == m) {
-                                val = z[c];
-                            }
-                        }
-                        v[e] = val;
-                    }
-                    *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-                }
-            }
-        }
-    }
-}
-
-void ck_launch_assemble_aux_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
-                                       const double* const* coefs, int metric, int i_pred, const double* pc,
-                                       const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
-                                       int64_t npad, const double* z, int64_t n0, int64_t N, int64_t col0,
-                                       double* out) {
-    if (mpad <= 0) return;
-    CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, pu, pu + mpad, pu + 2 * mpad};
-    CkSiteRef S{c, c + npad, c + 2 * npad, u, u + npad, u + 2 * npad};
-    k_assemble_aux_fast<<<dim3(CK_NB / 256, (unsigned)(mpad / 64)), dim3(256), 0, s>>>(blk, tabs, coefs, metric,
-                                                                                       i_pred, P, m, S, z, n0, N,
-                                                                                       col0, out);
+    return 0;
 }

@@ -19,28 +19,23 @@ void ck_launch_prep_sites(hipStream_t s, const double* coords, int64_t n, int me
 void ck_launch_table_nodes(hipStream_t s, const CkMatern* m, int metric, const double* q, int64_t n, double* out);
 void ck_launch_table_check(hipStream_t s, const CkMatern* m, int metric, CkTable tab, const double* coef,
                            unsigned long long* max_err_bits);
-// c: 3 x npad (exact coordinates), u: 3 x npad (chord vectors)
-void ck_launch_assemble_sigma_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
-                                         const double* const* coefs, int metric, const double* c, const double* u,
-                                         int64_t npad, int64_t n0, int64_t N, int64_t row0, int64_t nrows,
-                                         int64_t col0, double* out);
-void ck_launch_assemble_aux_panel_fast(hipStream_t s, const CkMatern* blk, const CkTable* tabs,
-                                       const double* const* coefs, int metric, int i_pred, const double* pc,
-                                       const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
-                                       int64_t npad, const double* z, int64_t n0, int64_t N, int64_t col0,
-                                       double* out);
+int ck_fallback_counter(hipStream_t s, int reset, unsigned long long* out);
+// Internal site order: process 0 in [0, n0), process 1 in [n0p, nend), n0p = roundup(n0, 64);
+// every other index below npad is padding (identity in Sigma, zero in the right-hand sides).
+struct CkLayout {
+    long n0, n0p, nend, npad;
+};
 // One block column of Sigma: rows [row0, row0 + nrows) x cols [col0, col0 + CK_NB), ld = CK_NB.
-// Sites are the stacked data sites (n0 of process 0, then N - n0 of process 1); entries with a
-// padded index (>= N) form an identity.
-void ck_launch_assemble_sigma_panel(hipStream_t s, const CkMatern* blk, int metric, const double* s0,
-                                    const double* s1, const double* s2, int64_t n0, int64_t N, int64_t row0,
-                                    int64_t nrows, int64_t col0, double* out);
+// c: 3 x npad exact-formula coordinates, u: 3 x npad chord vectors.  fast: table path.
+void ck_launch_assemble_sigma_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                                    const double* const* coefs, int metric, const double* c, const double* u,
+                                    CkLayout L, int64_t row0, int64_t nrows, int64_t col0, double* out);
 // One block column of the right-hand-side rows: rows = prediction sites p in [0, m) (row m = data
-// values z, rows > m zero), cols = stacked data sites [col0, col0 + CK_NB).
-void ck_launch_assemble_aux_panel(hipStream_t s, const CkMatern* blk, int metric, int i_pred, const double* p0,
-                                  const double* p1, const double* p2, int64_t m, int64_t mpad, const double* s0,
-                                  const double* s1, const double* s2, const double* z, int64_t n0, int64_t N,
-                                  int64_t col0, double* out);
+// values z, rows > m zero), cols = data sites [col0, col0 + CK_NB).
+void ck_launch_assemble_aux_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                                  const double* const* coefs, int metric, int i_pred, const double* pc,
+                                  const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
+                                  const double* z, CkLayout L, int64_t col0, double* out);
 // dense a x b block for one (i, j) Matern block; mode 0 = covariance, 1 = distance only
 void ck_launch_cov_dense(hipStream_t s, const CkMatern* blk_ij, int metric, int add_nugget, int mode,
                          const double* a0, const double* a1, const double* a2, int64_t a, const double* b0,

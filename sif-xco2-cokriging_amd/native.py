@@ -58,6 +58,7 @@ _PROTOS = {
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
     "ck_timings": [c_void_p, _dp, c_int],
+    "ck_table_fallbacks": [c_void_p, c_int, POINTER(c_int64)],
     "ck_table_info": [c_void_p, c_int, POINTER(c_int), POINTER(c_int), _dp, _dp, _dp],
     "ck_dev_gemm_nt": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                        c_int],
@@ -311,6 +312,11 @@ class Handle:
         _chk(lib().ck_table_info(self._h, int(block), byref(en), byref(ni), byref(ql), byref(qh), byref(er)))
         return dict(enabled=bool(en.value), n_intervals=ni.value, q_lo=ql.value, q_hi=qh.value,
                     max_rel_err=er.value)
+
+    def table_fallbacks(self, reset=True):
+        c = c_int64(0)
+        _chk(lib().ck_table_fallbacks(self._h, int(bool(reset)), byref(c)))
+        return c.value
 
     def timings(self):
         out = np.zeros(12)

@@ -129,23 +129,33 @@ def test_gemm_nt_mfma(native):
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
 
 
-def _assembled(native, params, coords, values, metric):
+def _assembled(native, params, coords, values, metric, exact=False):
     h, p = handle_for(native, params, metric)
     for k in range(p.n_procs):
         h.set_data(k, coords[k], values[k])
+    if exact:
+        h.set_option("exact_cov", 1)
     h.assemble_joint()
     return h, p
 
 
-def test_assemble_and_factor_vs_oracle(native):
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("tag", ["A", "R"])
+def test_assemble_and_factor_vs_oracle(native, exact, tag):
+    """Sigma entry by entry (tabulated and per-entry Bessel paths), then L against numpy."""
     g = load_golden("joint_solve")
-    coords = [g["coords0_A"], g["coords1_A"]]
-    values = [g["values0_A"], g["values1_A"]]
-    h, p = _assembled(native, g["params_A"], coords, values, HAV)
+    coords = [g[f"coords0_{tag}"], g[f"coords1_{tag}"]]
+    values = [g[f"values0_{tag}"], g[f"values1_{tag}"]]
+    h, p = _assembled(native, g[f"params_{tag}"], coords, values, HAV, exact=exact)
+    if not exact:
+        for b in range(3):
+            ti = h.table_info(b)
+            assert ti["enabled"] and ti["max_rel_err"] < 2e-13, ti
     N = 400
     S = orc.joint_cov(p, coords, HAV)
     low = h.debug_get_lower(N)
-    np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=1e-300)
+    # 5e-13 relative; entries below 1e-30 (e^-70 of the variance) only to 1e-30 absolute
+    np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=1e-30)
     assert h.factor() == 0
     L = h.debug_get_lower(N)
     Lref = np.linalg.cholesky(S)
