@@ -90,7 +90,7 @@ __device__ unsigned long long g_ck_fallback_entries = 0;
 __device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, int metric,
                                              int nug, double ac0, double ac1, double ac2, double au0, double au1,
                                              double au2, double bc0, double bc1, double bc2, double bu0, double bu1,
-                                             double bu2) {
+                                             double bu2, bool valid) {
     const bool same = (ac0 == bc0 && ac1 == bc1);   // h == 0 exactly (model.py:195-196)
     const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
     const double q = dx * dx + dy * dy + dz * dz;
@@ -99,7 +99,7 @@ __device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& t
     const double x = ck_table_x(in_tab ? q : tab.q_lo, &iv, tab.base);   // keep the lookup in range
     double val = m.amp * exp(ck_table_logrho(lcoef, tab.n_int, iv, x));
     if (same) val = nug ? m.amp + m.nugget : m.amp;
-    const bool slow = !same && !in_tab;
+    const bool slow = valid && !same && !in_tab;   // padding lanes never ask for the exact formulas
     const unsigned long long sl = __builtin_amdgcn_ballot_w64(slow);
     if (sl != 0ULL) {
         if (slow) val = exact_entry_call(&m, metric, nug, ac0, ac1, ac2, bc0, bc1, bc2);
@@ -178,12 +178,15 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
                 d2_t v;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    double val;
-                    if (FAST)
+                    double val = 0.0;
+                    const bool valid = rv[a] && cv[e];
+                    if (FAST) {
                         val = fast_entry(mb, ltab, lcoef, metric, nug, rc0[a], rc1[a], rc2[a], ru0[a], ru1[a], ru2[a],
-                                         cc0[e], cc1[e], cc2[e], cu0[e], cu1[e], cu2[e]);
-                    else
-                        val = ck_cov_entry(mb, pair_dist(metric, rc0[a], rc1[a], rc2[a], cc0[e], cc1[e], cc2[e]), nug);
+                                         cc0[e], cc1[e], cc2[e], cu0[e], cu1[e], cu2[e], valid);
+                    } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
+                        if (valid)
+                            val = exact_entry_call(&mb, metric, nug, rc0[a], rc1[a], rc2[a], cc0[e], cc1[e], cc2[e]);
+                    }
                     if (AUX) {
                         // rows: prediction sites | z | zero padding; padded columns are zero
                         if (!rv[a]) val = (r == m) ? zc[e] : 0.0;
