@@ -207,46 +207,72 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 }
 
 // ---------------------------------------------------------------------------------------
-// 64 x 64 Cholesky of a diagonal block (one workgroup, LDS resident)
+// 64 x 64 Cholesky of a diagonal block (one workgroup, register resident)
 // ---------------------------------------------------------------------------------------
-// Right-looking on the UNSCALED columns: at step j every element (i, k), j < k <= i, gets
-// a[i][k] -= a[i][j] a[k][j] / a[j][j]; the pivots a[j][j] are final after step j - 1, so the
-// scaling L[i][j] = a[i][j] / sqrt(a[j][j]) is applied once at the end.  One barrier per step.
+// Thread (bi, bk) = (t >> 4, t & 15) keeps the 4 x 4 block rows 4bi.., cols 4bk.. in registers.
+// Right-looking on the UNSCALED columns: at step j the owners of column j publish it through a
+// double-buffered LDS vector, then every thread updates a[i][k] -= a[i][j] a[k][j] / a[j][j] for
+// its elements with j < k <= i.  The pivots a[j][j] are final once step j - 1 is done, so the
+// scaling L[i][j] = a[i][j] / sqrt(a[j][j]) is applied once at the end.  One barrier per step,
+// no LDS read-modify-write.
 __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info) {
-    __shared__ double a[64][65];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        a[r][c] = A[r * ld + c];
-    }
-    __syncthreads();
-    const int i = tid >> 2, kb = (tid & 3) * 16;
-    bool failed = false;
-    for (int j = 0; j < 63; ++j) {
-        const double piv = a[j][j];
-        if (tid == 0 && !failed && !(piv > 0.0)) {
-            failed = true;
-            atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + j + 1));
-        }
-        if (i > j) {
-            const double f = a[i][j] * (1.0 / piv);
+    __shared__ double col[2][64];
+    __shared__ double pv[64];
+    const int t = threadIdx.x, bi = t >> 4, bk = t & 15;
+    const bool lower = bk <= bi;
+    double a[4][4];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int k = kb + kk;
-                if (k > j && k <= i) a[i][k] -= f * a[k][j];
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][c] = lower ? A[(long)(4 * bi + r) * ld + 4 * bk + c] : 0.0;
+    bool failed = false;
+    for (int jb = 0; jb < 16; ++jb) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * jb + jj;
+            double* cb = col[jj & 1];
+            if (bk == jb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cb[4 * bi + r] = a[r][jj];
+            }
+            __syncthreads();
+            const double piv = cb[j];
+            if (t == 0) {
+                pv[j] = piv;
+                if (!failed && !(piv > 0.0)) {
+                    failed = true;
+                    atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + j + 1));
+                }
+            }
+            if (lower && bk >= jb) {
+                const double rp = 1.0 / piv;
+                double li[4], lk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) li[r] = cb[4 * bi + r] * rp;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lk[c] = cb[4 * bk + c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool upd = (bk > jb || c > jj) && (4 * bk + c <= 4 * bi + r);
+                        if (upd) a[r][c] -= li[r] * lk[c];
+                    }
             }
         }
-        __syncthreads();
     }
-    if (tid == 0 && !failed && !(a[63][63] > 0.0))
-        atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + 64));
-    // scale and write back the lower triangle
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        if (c <= r) {
-            const double d = sqrt(a[c][c]);
-            A[r * ld + c] = (c == r) ? d : a[r][c] / d;
-        }
+    __syncthreads();
+    if (lower) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = 4 * bi + r, k = 4 * bk + c;
+                if (k <= i) {
+                    const double d = sqrt(pv[k]);
+                    A[(long)i * ld + k] = (k == i) ? d : a[r][c] / d;
+                }
+            }
     }
 }
 
@@ -255,18 +281,20 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 }
 
 // ---------------------------------------------------------------------------------------
-// X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
+// X L^T = A  (64 columns, rows independent): one row per lane
 // ---------------------------------------------------------------------------------------
+// The 64 x 64 tile of A goes through LDS for coalesced global access; each lane then holds its
+// row in registers and substitutes right-looking.  L is read with wave-uniform addresses straight
+// from global memory, which the compiler turns into scalar (SMEM) loads feeding v_fma_f64 as an
+// SGPR operand: no LDS traffic in the substitution loop.
 __global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
                                                 long ldl) {
-    __shared__ double Ls[64][65];
     __shared__ double T[64][65];
     const int lane = threadIdx.x;
     double* base = A + (long)blockIdx.x * 64 * ld;
     for (int idx = lane; idx < 64 * 64; idx += 64) {
         const int r = idx >> 6, c = idx & 63;
-        Ls[r][c] = L[r * ldl + c];
-        T[r][c] = base[r * ld + c];
+        T[r][c] = base[(long)r * ld + c];
     }
     __syncthreads();
     double x[64];
@@ -274,16 +302,16 @@ __global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, 
     for (int c = 0; c < 64; ++c) x[c] = T[lane][c];
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
-        x[c] = x[c] / Ls[c][c];
+        x[c] = x[c] / L[c * ldl + c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
+        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * L[c2 * ldl + c];
     }
 #pragma unroll
     for (int c = 0; c < 64; ++c) T[lane][c] = x[c];
     __syncthreads();
     for (int idx = lane; idx < 64 * 64; idx += 64) {
         const int r = idx >> 6, c = idx & 63;
-        base[r * ld + c] = T[r][c];
+        base[(long)r * ld + c] = T[r][c];
     }
 }
 
