@@ -145,6 +145,10 @@ int ck_vario_end(ck_handle* h);
 int ck_debug_get_lower(ck_handle* h, double* out_host, int64_t n);
 /* Raw lane/register -> (row, col) map of v_mfma_f64_16x16x4_f64: out[64*4*3] ints (row, col, k-map check). */
 int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
+/* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,
+ * `waves_per_simd` waves on every SIMD of the chip): the measured ceiling the GEMM kernels are
+ * compared with, next to the datasheet 78.6 TFLOP/s. */
+int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* tflops);
 /* Stage timings of the last calls in milliseconds (HIP events):
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update

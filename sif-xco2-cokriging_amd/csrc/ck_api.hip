@@ -971,6 +971,29 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     return 0;
 }
 
+extern "C" int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* tflops) {
+    CHKH(h);
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return fail("bad arguments");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    const int cus = prop.multiProcessorCount;
+    double* sink = nullptr;
+    HIPCHK(hipMalloc((void**)&sink, 8));
+    const int threads = 256, blocks = cus * waves_per_simd;   // 4 waves per block = one per SIMD
+    ck_launch_mfma_peak(h->stream, blocks, threads, 10, sink);   // warm-up
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    ck_launch_mfma_peak(h->stream, blocks, threads, iters, sink);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    const double flops = (double)blocks * (threads / 64) * (double)iters * 16.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipFree(sink);
+    return 0;
+}
+
 extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     CHKH(h);
     if (!name) return fail("null option name");

@@ -381,3 +381,24 @@ __global__ void k_mfma_probe(int32_t* out) {
 }
 
 void ck_launch_mfma_probe(hipStream_t s, int32_t* out) { k_mfma_probe<<<dim3(1), dim3(64), 0, s>>>(out); }
+
+// FP64 MFMA issue-rate microbenchmark: `waves_per_simd` waves per SIMD, 16 independent
+// accumulators each, operands in registers, no memory traffic in the loop.
+__global__ void k_mfma_peak(int iters, double* sink) {
+    d4_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+void ck_launch_mfma_peak(hipStream_t s, int blocks, int threads, int iters, double* sink) {
+    k_mfma_peak<<<dim3(blocks), dim3(threads), 0, s>>>(iters, sink);
+}

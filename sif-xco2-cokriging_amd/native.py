@@ -56,6 +56,7 @@ _PROTOS = {
     "ck_vario_end": [c_void_p],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
+    "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
     "ck_timings": [c_void_p, _dp, c_int],
     "ck_table_fallbacks": [c_void_p, c_int, POINTER(c_int64)],
@@ -317,6 +318,11 @@ class Handle:
         c = c_int64(0)
         _chk(lib().ck_table_fallbacks(self._h, int(bool(reset)), byref(c)))
         return c.value
+
+    def mfma_peak(self, waves_per_simd=1, iters=20000):
+        t = c_double(0)
+        _chk(lib().ck_debug_mfma_peak(self._h, int(waves_per_simd), int(iters), byref(t)))
+        return t.value
 
     def timings(self):
         out = np.zeros(12)
