@@ -148,7 +148,7 @@ int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,
  * `waves_per_simd` waves on every SIMD of the chip): the measured ceiling the GEMM kernels are
  * compared with, next to the datasheet 78.6 TFLOP/s. */
-int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* tflops);
+int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3 /* TFLOP/s, shader MHz, cycles per MFMA per wave */);
 /* Stage timings of the last calls in milliseconds (HIP events):
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update

@@ -971,25 +971,29 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     return 0;
 }
 
-extern "C" int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* tflops) {
+extern "C" int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3) {
     CHKH(h);
     if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return fail("bad arguments");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     const int cus = prop.multiProcessorCount;
     double* sink = nullptr;
-    HIPCHK(hipMalloc((void**)&sink, 8));
+    HIPCHK(hipMalloc((void**)&sink, 32));
     const int threads = 256, blocks = cus * waves_per_simd;   // 4 waves per block = one per SIMD
-    ck_launch_mfma_peak(h->stream, blocks, threads, 10, sink);   // warm-up
+    ck_launch_mfma_peak(h->stream, blocks, waves_per_simd, 10, sink);   // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    ck_launch_mfma_peak(h->stream, blocks, threads, iters, sink);
+    const int nacc = ck_launch_mfma_peak(h->stream, blocks, waves_per_simd, iters, sink);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipGetLastError());
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    const double flops = (double)blocks * (threads / 64) * (double)iters * 16.0 * 2048.0;
-    *tflops = flops / (ms * 1e-3) / 1e12;
+    const double flops = (double)blocks * (threads / 64) * (double)iters * nacc * 2048.0;
+    double hs[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(hs, sink, 32, hipMemcpyDeviceToHost));
+    out3[0] = flops / (ms * 1e-3) / 1e12;                           // TFLOP/s
+    out3[1] = hs[2] > 0 ? hs[1] / hs[2] * 100.0 : 0.0;              // in-kernel shader clock, MHz
+    out3[2] = hs[1] / ((double)iters * nacc);   // cycles per MFMA of one wave
     (void)hipFree(sink);
     return 0;
 }

@@ -65,7 +65,7 @@ void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const
 void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
                            double c0, double* pred, double* err);
 void ck_launch_mfma_probe(hipStream_t s, int32_t* out);
-void ck_launch_mfma_peak(hipStream_t s, int blocks, int threads, int iters, double* sink);
+int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters, double* sink);
 
 // ---- empirical variogram (ck_vario.hip) ----------------------------------------------------
 #define CK_VG_MAXBINS 36

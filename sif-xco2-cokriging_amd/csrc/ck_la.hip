@@ -384,21 +384,38 @@ void ck_launch_mfma_probe(hipStream_t s, int32_t* out) { k_mfma_probe<<<dim3(1),
 
 // FP64 MFMA issue-rate microbenchmark: `waves_per_simd` waves per SIMD, 16 independent
 // accumulators each, operands in registers, no memory traffic in the loop.
-__global__ void k_mfma_peak(int iters, double* sink) {
-    d4_t acc[16];
+template <int NACC, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_mfma_peak(int iters, double* sink) {
+    d4_t acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, (double)i};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz ticks of the loop
+        sink[1] = (double)(t1 - t0);
+        sink[2] = (double)(r1 - r0);
+    }
 }
 
-void ck_launch_mfma_peak(hipStream_t s, int blocks, int threads, int iters, double* sink) {
-    k_mfma_peak<<<dim3(blocks), dim3(threads), 0, s>>>(iters, sink);
+// returns the number of MFMAs per loop iteration
+int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters, double* sink) {
+    if (waves_per_simd >= 4) {
+        k_mfma_peak<8, 4><<<dim3(blocks), dim3(256), 0, s>>>(iters, sink);
+        return 8;
+    }
+    if (waves_per_simd >= 2) {
+        k_mfma_peak<16, 2><<<dim3(blocks), dim3(256), 0, s>>>(iters, sink);
+        return 16;
+    }
+    k_mfma_peak<16, 1><<<dim3(blocks), dim3(256), 0, s>>>(iters, sink);
+    return 16;
 }

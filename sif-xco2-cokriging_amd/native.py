@@ -320,9 +320,9 @@ class Handle:
         return c.value
 
     def mfma_peak(self, waves_per_simd=1, iters=20000):
-        t = c_double(0)
-        _chk(lib().ck_debug_mfma_peak(self._h, int(waves_per_simd), int(iters), byref(t)))
-        return t.value
+        out = np.zeros(3)
+        _chk(lib().ck_debug_mfma_peak(self._h, int(waves_per_simd), int(iters), _p(out)))
+        return dict(tflops=out[0], shader_mhz=out[1], cycles_per_mfma_per_wave=out[2])
 
     def timings(self):
         out = np.zeros(12)
