@@ -22,120 +22,142 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------
 // Workgroup tile 256 x BN (BN = 128 or 64), K step 16, 512 threads = 8 waves laid out
 // 4 (M) x 2 (N); each wave owns 64 x (BN/2) = 4 x WN MFMA tiles of 16 x 16, i.e. 16 or 8
-// independent accumulators (the f64 MFMA is 64 cycles deep on the SIMD, so one wave's
-// own accumulators already cover its dependent-issue latency).
+// independent accumulators.  One wave per SIMD already saturates the f64 MFMA pipe when it
+// issues back to back (measured by ck_debug_mfma_peak: 64 cycles per v_mfma_f64_16x16x4_f64,
+// 77.8 TFLOP/s chip-wide), so everything else in the loop only has to stay out of the way.
 //
-// v_mfma_f64_16x16x4_f64 operand map (cdna_hip_programming.md section 3, probed by
-// ck_debug_mfma_probe):  lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
-// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+// v_mfma_f64_16x16x4_f64 operand map (probed by ck_debug_mfma_probe): lane l supplies
+// A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15].  The contraction index of one MFMA may be ANY four
+// k as long as A and B agree, so lane group g = l >> 4 reads the two CONSECUTIVE k = 2g, 2g + 1
+// of an 8-wide k block with one ds_read_b128 and feeds them to two MFMAs.
 //
-// LDS rows hold 16 doubles of K plus 2 doubles of padding (144 B): for ds_read_b64 the 32
-// lanes of a half-wave (16 rows x 2 k) then hit 64 distinct banks.
-#define GEMM_LDK 18
+// LDS image of a K step (16 k = 8 k-pairs p): plane p holds the 16-byte pair p of every row,
+// rows XOR-swizzled by p in their low 3 bits:   byte(row, p) = p * rows * 16 + (row ^ p) * 16.
+//   - staging writes (ds_write_b128, 8 consecutive lanes = the 8 pairs of ONE row, so the global
+//     loads stay coalesced in full 128-byte lines) land on 8 distinct rows -> conflict free;
+//   - operand reads (ds_read_b128, serviced in the fixed 16-lane groups of the hardware) cover
+//     all 64 banks exactly once per group -> conflict free.
+// C is loaded into the accumulators up front and A is negated on its way into LDS
+// (acc = C + (-A) B^T), so the epilogue is stores only.
 #define GEMM_BK 16
 
 template <int WN>
 __device__ __forceinline__ void gemm_tile(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
                                           const double* __restrict__ B, long ldb, long r0, long c0, int K,
-                                          double* lds) {
+                                          char* lds) {
     constexpr int BN = WN * 32;
-    constexpr int BCH = BN * 8 / 512;  // 16-byte chunks of the B tile per thread (2 or 1)
-    constexpr int STAGE = (CK_BM + BN) * GEMM_LDK;   // doubles per LDS stage: A tile then B tile
-    constexpr int BOFF = CK_BM * GEMM_LDK;
+    constexpr int BCH = BN * 8 / 512;            // 16-byte chunks of the B tile per thread (2 or 1)
+    constexpr int PLANE_A = CK_BM * 16;          // bytes per k-pair plane
+    constexpr int PLANE_B = BN * 16;
+    constexpr int BOFF = 8 * PLANE_A;            // B planes follow the 8 A planes
+    constexpr int STAGE = 8 * (PLANE_A + PLANE_B);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int li = lane & 15, kq = lane >> 4;
+    const int li = lane & 15, g = lane >> 4;
 
-    // global -> register staging assignments (one 16-byte chunk = 2 doubles of K)
-    const double* a_src[4];
-    int a_dst[4];
+    // Wave-uniform 64-bit bases + 32-bit per-thread offsets (saddr addressing: no 64-bit address
+    // pairs in VGPRs; the accumulators need the room).
+    const double* Ab = A + r0 * lda;
+    const double* Bb = B + c0 * ldb;
+    double* Cb = C + r0 * ldc + c0;
+    // global -> register staging: chunk id -> (row = id >> 3, pair p = id & 7)
+    unsigned a_src[4], b_src[BCH];
+    int a_dst[4], b_dst[BCH];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
-        a_src[u] = A + (r0 + row) * lda + ch * 2;
-        a_dst[u] = row * GEMM_LDK + ch * 2;
+        const int id = tid + 512 * u, row = id >> 3, p = id & 7;
+        a_src[u] = (unsigned)(row * (int)lda + p * 2);
+        a_dst[u] = p * PLANE_A + ((row ^ p) << 4);
     }
-    const double* b_src[BCH];
-    int b_dst[BCH];
 #pragma unroll
     for (int u = 0; u < BCH; ++u) {
-        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
-        b_src[u] = B + (c0 + row) * ldb + ch * 2;
-        b_dst[u] = row * GEMM_LDK + ch * 2;
+        const int id = tid + 512 * u, row = id >> 3, p = id & 7;
+        b_src[u] = (unsigned)(row * (int)ldb + p * 2);
+        b_dst[u] = BOFF + p * PLANE_B + ((row ^ p) << 4);
     }
+    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * (WN * 16) + li);
+
+    // first K step in flight while C streams into the accumulators
+    d2_t ra[4], rb[BCH];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(Ab + a_src[u]);
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(Bb + b_src[u]);
 
     d4_t acc[4][WN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 4; ++r) {
+            const double* rowp = Cb + (long)(i * 16 + 4 * r) * ldc;   // wave-uniform -> SGPR base
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j][r] = rowp[c_off + j * 16];
+        }
 
-    d2_t ra[4], rb[BCH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u]);
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(lds + a_dst[u]) = -ra[u];
 #pragma unroll
-    for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(lds + a_dst[u]) = ra[u];
-#pragma unroll
-    for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(lds + BOFF + b_dst[u]) = rb[u];
+    for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(lds + b_dst[u]) = rb[u];
     __syncthreads();
 
-    const int nst = K / GEMM_BK;
-    const int a_rd = (wm * 64 + li) * GEMM_LDK + kq;
-    const int b_rd = (wn * (WN * 16) + li) * GEMM_LDK + kq;
+    // operand read offsets for the two 8-wide k blocks (kb = 0, 1): pair p = 4 kb + g
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int p = 4 * kb + g;
+        a_rd[kb] = p * PLANE_A + ((wm * 64 + (li ^ p)) << 4);
+        b_rd[kb] = BOFF + p * PLANE_B + ((wn * (WN * 16) + (li ^ p)) << 4);
+    }
 
+    const int nst = K / GEMM_BK;
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         const bool more = (st + 1 < nst);
         if (more) {
             const int k0 = (st + 1) * GEMM_BK;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u] + k0);
+            for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(Ab + k0 + a_src[u]);
 #pragma unroll
-            for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u] + k0);
+            for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(Bb + k0 + b_src[u]);
         }
-        const double* as = lds + cur * STAGE + a_rd;
-        const double* bs = lds + cur * STAGE + BOFF + b_rd;
+        const char* sb = lds + cur * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[WN];
+        for (int kb = 0; kb < 2; ++kb) {
+            d2_t af[4], bf[WN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = as[i * 16 * GEMM_LDK + kk * 4];
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 256);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = bs[j * 16 * GEMM_LDK + kk * 4];
+            for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 256);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            double* nx = lds + (cur ^ 1) * STAGE;
+            char* nx = lds + (cur ^ 1) * STAGE;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(nx + a_dst[u]) = ra[u];
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(nx + a_dst[u]) = -ra[u];
 #pragma unroll
-            for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(nx + BOFF + b_dst[u]) = rb[u];
+            for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(nx + b_dst[u]) = rb[u];
         }
         __syncthreads();
     }
 
-    // epilogue: C -= acc.  Register r of lane l is D[(l >> 4) + 4 r][l & 15].
+    // epilogue: stores only.  Register r of lane l is D[(l >> 4) + 4 r][l & 15].
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const long col = c0 + wn * (WN * 16) + j * 16 + li;
+        for (int r = 0; r < 4; ++r) {
+            double* rowp = Cb + (long)(i * 16 + 4 * r) * ldc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = r0 + wm * 64 + i * 16 + kq + 4 * r;
-                double* p = C + row * ldc + col;
-                *p = *p - acc[i][j][r];
-            }
+            for (int j = 0; j < WN; ++j) rowp[c_off + j * 16] = acc[i][j][r];
         }
-    }
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks b and b + 8 share an XCD (and its L2);
@@ -152,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long
                                                      int tiles_n, int K, int lower, long diag_off, long sC, long sA,
                                                      long sB) {
     constexpr int BN = WN * 32;
-    __shared__ double lds[2 * (CK_BM + BN) * GEMM_LDK];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * (CK_BM + BN) * 16];
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * CK_BM, c0 = (long)tn * BN;
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long
 __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restrict__ sigptr,
                                                          const double* __restrict__ P, int K, int J0, int Jstep,
                                                          long Npad) {
-    __shared__ double lds[2 * (CK_BM + 128) * GEMM_LDK];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * (CK_BM + 128) * 16];
     const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
     const int tiles_m = (int)(M / CK_BM), tiles_n = CK_NB / 128;
@@ -281,19 +303,19 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 }
 
 // ---------------------------------------------------------------------------------------
-// X L^T = A  (64 columns, rows independent): one row per lane
+// X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
 // ---------------------------------------------------------------------------------------
-// The 64 x 64 tile of A goes through LDS for coalesced global access; each lane then holds its
-// row in registers and substitutes right-looking.  L is read with wave-uniform addresses straight
-// from global memory, which the compiler turns into scalar (SMEM) loads feeding v_fma_f64 as an
-// SGPR operand: no LDS traffic in the substitution loop.
+// (Feeding L through scalar loads instead of LDS was tried and measured 2x slower:
+//  90.7 us against 43.7 us per launch at N = 40k.)
 __global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
                                                 long ldl) {
+    __shared__ double Ls[64][65];
     __shared__ double T[64][65];
     const int lane = threadIdx.x;
     double* base = A + (long)blockIdx.x * 64 * ld;
     for (int idx = lane; idx < 64 * 64; idx += 64) {
         const int r = idx >> 6, c = idx & 63;
+        Ls[r][c] = L[r * ldl + c];
         T[r][c] = base[(long)r * ld + c];
     }
     __syncthreads();
@@ -302,9 +324,9 @@ __global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, 
     for (int c = 0; c < 64; ++c) x[c] = T[lane][c];
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
-        x[c] = x[c] / L[c * ldl + c];
+        x[c] = x[c] / Ls[c][c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * L[c2 * ldl + c];
+        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
     }
 #pragma unroll
     for (int c = 0; c < 64; ++c) T[lane][c] = x[c];
