@@ -101,6 +101,10 @@ __device__ __forceinline__ void gemm_tile(double* __restrict__ C, long ldc, cons
     for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(lds + a_dst[u]) = -ra[u];
 #pragma unroll
     for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(lds + b_dst[u]) = rb[u];
+    // Drain the C loads HERE.  Otherwise the first MFMA of the loop body carries an
+    // s_waitcnt vmcnt(0) for them on every iteration, which also waits for the next K step's
+    // prefetch loads issued just above it and so serialises load latency with the MFMAs.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
     // operand read offsets for the two 8-wide k blocks (kb = 0, 1): pair p = 4 kb + g
