@@ -1005,6 +1005,10 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->time_gemm = value != 0;
         return 0;
     }
+    if (!strcmp(name, "gemm_variant")) {   // process-wide A/B switch of the GEMM tile structure
+        g_ck_gemm_variant = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "exact_cov")) {   // 1: per-entry Bessel evaluation instead of the tables
         h->exact_cov = value != 0;
         return 0;

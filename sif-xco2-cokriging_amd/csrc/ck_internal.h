@@ -44,6 +44,7 @@ void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, c
                         double* out);
 
 // ---- dense linear algebra (ck_la.hip) ----------------------------------------
+extern int g_ck_gemm_variant;   // A/B switch of the GEMM tile structure (option "gemm_variant")
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T on FP64 MFMA.
 // M % 256 == 0, N % 64 == 0, K % 16 == 0.  lower: skip tiles whose rows are all above the
 // diagonal  row + diag_off == col.

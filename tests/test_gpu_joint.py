@@ -98,11 +98,14 @@ def test_cov_dense_blocks(native, tag):
         np.testing.assert_allclose(c0, g[f"c0_{tag}_{i}"], rtol=5e-13, atol=1e-300)
 
 
-def test_gemm_nt_mfma(native):
+@pytest.mark.parametrize("variant", [4, 0, 1, 2])
+def test_gemm_nt_mfma(native, variant):
+    """every tile structure of the MFMA GEMM (option gemm_variant) against torch fp64"""
     import torch
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
     h = native.Handle(0)
+    h.set_option("gemm_variant", variant)
     for (M, N, K, lower) in ((256, 128, 16, False), (512, 256, 64, False), (768, 192, 64, False),
                              (1024, 512, 512, True), (256, 64, 64, False)):
         A = torch.randn(M, K, dtype=torch.float64, device=dev)
@@ -117,16 +120,18 @@ def test_gemm_nt_mfma(native):
         if lower:
             # tiles strictly above the diagonal are skipped (left untouched)
             BN = 128 if N % 128 == 0 else 64
+            BM = 128 if (variant == 4 and N % 128 == 0) else 256
             c0 = C0.cpu().numpy()
-            for tm in range(M // 256):
+            for tm in range(M // BM):
                 for tn in range(N // BN):
-                    blk = (slice(tm * 256, tm * 256 + 256), slice(tn * BN, tn * BN + BN))
-                    if tm * 256 + 255 < tn * BN:
+                    blk = (slice(tm * BM, tm * BM + BM), slice(tn * BN, tn * BN + BN))
+                    if tm * BM + BM - 1 < tn * BN:
                         assert np.array_equal(got[blk], c0[blk])
                     else:
                         np.testing.assert_allclose(got[blk], ref[blk], rtol=1e-12, atol=1e-11)
         else:
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
+    h.set_option("gemm_variant", 4)
 
 
 def _assembled(native, params, coords, values, metric, exact=False):
