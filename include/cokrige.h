@@ -165,7 +165,9 @@ int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, doubl
  * or beyond its upper end) since the last reset, over all handles of this process. */
 int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events;
- * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables. */
+ * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
+ * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
+ * of panel K (ck_factor, ck_predict); "gemm_variant" selects the GEMM tile structure (A/B tests). */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);
 /* Plain C -= A B^T on device buffers through the MFMA kernel (tests / microbenchmarks).
  * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), all row-major device doubles;

@@ -106,6 +106,11 @@ struct ck_handle {
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // look-ahead: the panel step of column K+1 runs on a second (high-priority) stream under the
+    // trailing update of panel K
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
+    bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
 extern "C" const char* ck_last_error(void) { return g_err.c_str(); }
@@ -155,6 +160,11 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
     h->stream = h->own_stream;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+    }
     HIPCHK(hipMalloc((void**)&h->d_blk, 3 * sizeof(CkMatern)));
     HIPCHK(hipMalloc((void**)&h->d_info, sizeof(long long)));
     HIPCHK(hipMemset(h->d_info, 0, sizeof(long long)));
@@ -182,6 +192,9 @@ extern "C" int ck_destroy(ck_handle* h) {
     }
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
+    for (auto e : h->ev_col) (void)hipEventDestroy(e);
+    for (auto e : h->ev_pan) (void)hipEventDestroy(e);
+    if (h->side) (void)hipStreamDestroy(h->side);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -562,25 +575,79 @@ static void gemm_timed_collect(ck_handle* h, int slot) {
     h->gemm_ev_used = 0;
 }
 
+// ---- the building blocks, on an explicit stream --------------------------------------------------
+// two-level panel step on block column K: 8 x (64 x 64 Cholesky, row solves, K = 64 update)
+static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
+    double* P = h->sig[K];
+    const int64_t R = h->Npad - (int64_t)K * CK_NB;
+    for (int q = 0; q < CK_NB / CK_IB; ++q) {
+        double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
+        ck_launch_potrf64(st, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info);
+        const int64_t r1 = (int64_t)(q + 1) * CK_IB;
+        ck_launch_trsm64(st, P + r1 * CK_NB + q * CK_IB, CK_NB, R - r1, diag, CK_NB);
+        const int64_t ncols = CK_NB - r1;
+        if (ncols > 0) {
+            const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
+            ck_launch_gemm_nt(st, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
+                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
+        }
+    }
+}
+
+// trailing update of the locally owned block columns J in [Jlo, Jhi] by panel K
+static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi, hipStream_t st, bool timed) {
+    int J0 = Jlo;
+    while (J0 <= Jhi && (J0 % h->world) != h->rank) ++J0;
+    if (J0 > Jhi) return;
+    const int nJ = (Jhi - J0) / h->world + 1;
+    if (timed) gemm_timed_begin(h);
+    ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
+    if (timed) gemm_timed_end(h);
+}
+
+// forward substitution of the right-hand-side rows with the diagonal block of panel K
+static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
+    double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
+    for (int q = 0; q < CK_NB / CK_IB; ++q) {
+        const double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
+        ck_launch_trsm64(st, X + q * CK_IB, CK_NB, h->mpad, diag, CK_NB);
+        const int64_t r1 = (int64_t)(q + 1) * CK_IB;
+        const int64_t ncols = CK_NB - r1;
+        if (ncols > 0)
+            ck_launch_gemm_nt(st, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB, h->mpad,
+                              ncols, CK_IB, 0, 0, 1, 0, 0, 0);
+    }
+}
+
+// aux[J] -= aux[K] * P[(J-K)*NB .., :]^T for J in [Jlo, Jhi], batched over J
+static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi, hipStream_t st, bool timed) {
+    const int nJ = Jhi - Jlo + 1;
+    if (nJ <= 0) return;
+    double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
+    if (timed) gemm_timed_begin(h);
+    ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
+                      P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
+                      h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
+    if (timed) gemm_timed_end(h);
+}
+
+static int ensure_events(ck_handle* h) {
+    while ((int)h->ev_col.size() < h->nK + 1) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        h->ev_col.push_back(a);
+        h->ev_pan.push_back(b);
+    }
+    return 0;
+}
+
 extern "C" int ck_panel_factor(ck_handle* h, int K) {
     CHKH(h);
     if (!h->assembled) return fail("ck_assemble_joint has not been called");
     if (K < 0 || K >= h->nK) return fail("bad panel index");
-    double* P = h->sig[K];
-    if (!P) return fail("panel " + std::to_string(K) + " is not owned by this rank");
-    const int64_t R = h->Npad - (int64_t)K * CK_NB;
-    for (int q = 0; q < CK_NB / CK_IB; ++q) {
-        double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
-        ck_launch_potrf64(h->stream, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info);
-        const int64_t r1 = (int64_t)(q + 1) * CK_IB;
-        ck_launch_trsm64(h->stream, P + r1 * CK_NB + q * CK_IB, CK_NB, R - r1, diag, CK_NB);
-        const int64_t ncols = CK_NB - r1;
-        if (ncols > 0) {
-            const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
-            ck_launch_gemm_nt(h->stream, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
-                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
-        }
-    }
+    if (!h->sig[K]) return fail("panel " + std::to_string(K) + " is not owned by this rank");
+    panel_factor_on(h, K, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -589,36 +656,10 @@ extern "C" int ck_panel_apply(ck_handle* h, int K, int what) {
     CHKH(h);
     if (K < 0 || K >= h->nK) return fail("bad panel index");
     const double* P = panel_src(h, K);
-    if (what & CK_APPLY_SIGMA) {
-        // first owned J > K
-        int J0 = K + 1;
-        while (J0 < h->nK && (J0 % h->world) != h->rank) ++J0;
-        if (J0 < h->nK) {
-            const int nJ = (h->nK - 1 - J0) / h->world + 1;
-            gemm_timed_begin(h);
-            ck_launch_syrk_panels(h->stream, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
-            gemm_timed_end(h);
-        }
-    }
+    if (what & CK_APPLY_SIGMA) apply_sigma_on(h, K, P, K + 1, h->nK - 1, h->stream, true);
     if ((what & CK_APPLY_AUX) && h->mpad > 0) {
-        double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
-        for (int q = 0; q < CK_NB / CK_IB; ++q) {
-            const double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
-            ck_launch_trsm64(h->stream, X + q * CK_IB, CK_NB, h->mpad, diag, CK_NB);
-            const int64_t r1 = (int64_t)(q + 1) * CK_IB;
-            const int64_t ncols = CK_NB - r1;
-            if (ncols > 0)
-                ck_launch_gemm_nt(h->stream, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB,
-                                  h->mpad, ncols, CK_IB, 0, 0, 1, 0, 0, 0);
-        }
-        const int nJ = h->nK - 1 - K;
-        if (nJ > 0) {
-            gemm_timed_begin(h);
-            // aux[J] -= aux[K] * P[(J-K)*NB .. , :]^T for all J > K, batched over J
-            ck_launch_gemm_nt(h->stream, X + h->mpad * CK_NB, CK_NB, X, CK_NB, P + (int64_t)CK_NB * CK_NB, CK_NB,
-                              h->mpad, CK_NB, CK_NB, 0, 0, nJ, h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
-            gemm_timed_end(h);
-        }
+        aux_inner_on(h, K, P, h->stream);
+        aux_update_on(h, K, P, K + 1, h->nK - 1, h->stream, true);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -640,9 +681,28 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
     h->gemm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int K = 0; K < h->nK; ++K) {
-        if (ck_panel_factor(h, K)) return -1;
-        if (ck_panel_apply(h, K, CK_APPLY_SIGMA)) return -1;
+    if (!h->lookahead) {
+        for (int K = 0; K < h->nK; ++K) {
+            if (ck_panel_factor(h, K)) return -1;
+            if (ck_panel_apply(h, K, CK_APPLY_SIGMA)) return -1;
+        }
+    } else {
+        // Look-ahead: as soon as panel K has updated block column K + 1, the panel step of K + 1
+        // starts on the side stream and runs under the update of the columns K + 2.. by panel K.
+        if (ensure_events(h)) return -1;
+        panel_factor_on(h, 0, h->stream);
+        for (int K = 0; K < h->nK; ++K) {
+            if (K > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pan[K], 0));
+            if (K + 1 < h->nK) {
+                apply_sigma_on(h, K, h->sig[K], K + 1, K + 1, h->stream, false);
+                HIPCHK(hipEventRecord(h->ev_col[K + 1], h->stream));
+                HIPCHK(hipStreamWaitEvent(h->side, h->ev_col[K + 1], 0));
+                panel_factor_on(h, K + 1, h->side);
+                HIPCHK(hipEventRecord(h->ev_pan[K + 1], h->side));
+                apply_sigma_on(h, K, h->sig[K], K + 2, h->nK - 1, h->stream, true);
+            }
+        }
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     if (ck_factor_info(h, info)) return -1;
@@ -730,8 +790,25 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, h->stream));
-    for (int K = 0; K < h->nK; ++K)
-        if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    if (!h->lookahead) {
+        for (int K = 0; K < h->nK; ++K)
+            if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    } else {
+        if (ensure_events(h)) return -1;
+        aux_inner_on(h, 0, h->sig[0], h->stream);
+        for (int K = 0; K < h->nK; ++K) {
+            if (K > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pan[K], 0));
+            if (K + 1 < h->nK) {
+                aux_update_on(h, K, h->sig[K], K + 1, K + 1, h->stream, false);
+                HIPCHK(hipEventRecord(h->ev_col[K + 1], h->stream));
+                HIPCHK(hipStreamWaitEvent(h->side, h->ev_col[K + 1], 0));
+                aux_inner_on(h, K + 1, h->sig[K + 1], h->side);
+                HIPCHK(hipEventRecord(h->ev_pan[K + 1], h->side));
+                aux_update_on(h, K, h->sig[K], K + 2, h->nK - 1, h->stream, true);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(e1, h->stream));
     if (ck_aux_finish(h, pred, pred_err)) return -1;
     float ms = 0;
@@ -1007,6 +1084,10 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "gemm_variant")) {   // process-wide A/B switch of the GEMM tile structure
         g_ck_gemm_variant = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
+        h->lookahead = value != 0;
         return 0;
     }
     if (!strcmp(name, "exact_cov")) {   // 1: per-entry Bessel evaluation instead of the tables

@@ -792,23 +792,28 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 // ---------------------------------------------------------------------------------------
 // X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
 // ---------------------------------------------------------------------------------------
-// (Feeding L through scalar loads instead of LDS was tried and measured 2x slower:
-//  90.7 us against 43.7 us per launch at N = 40k.)
-__global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
-                                                long ldl) {
+// 256 threads = 256 rows per workgroup; the 64 x 64 factor sits once in LDS (33 KB) and is read
+// with wave-uniform addresses (broadcast); every lane keeps its row in registers and substitutes
+// right-looking.  Rows go straight between global memory and registers (each lane owns 512
+// contiguous bytes), so LDS holds only L and eight waves fit on a CU.
+// (Feeding L through scalar loads instead of LDS was tried and measured 2x slower.)
+__global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
+                                                    long ldl) {
     __shared__ double Ls[64][65];
-    __shared__ double T[64][65];
-    const int lane = threadIdx.x;
-    double* base = A + (long)blockIdx.x * 64 * ld;
-    for (int idx = lane; idx < 64 * 64; idx += 64) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
         Ls[r][c] = L[r * ldl + c];
-        T[r][c] = base[(long)r * ld + c];
     }
-    __syncthreads();
+    double* row = A + ((long)blockIdx.x * 256 + tid) * ld;
     double x[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) x[c] = T[lane][c];
+    for (int c = 0; c < 64; c += 2) {
+        const d2_t v = *reinterpret_cast<const d2_t*>(row + c);
+        x[c] = v[0];
+        x[c + 1] = v[1];
+    }
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         x[c] = x[c] / Ls[c][c];
@@ -816,17 +821,54 @@ __global__ __launch_bounds__(64) void k_trsm64(double* __restrict__ A, long ld, 
         for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
     }
 #pragma unroll
-    for (int c = 0; c < 64; ++c) T[lane][c] = x[c];
-    __syncthreads();
-    for (int idx = lane; idx < 64 * 64; idx += 64) {
+    for (int c = 0; c < 64; c += 2) {
+        d2_t v;
+        v[0] = x[c];
+        v[1] = x[c + 1];
+        *reinterpret_cast<d2_t*>(row + c) = v;
+    }
+}
+
+// nrows % 256 == 0 is guaranteed by the callers except for panel-internal steps, where the
+// slab starts 64 (q + 1) rows into a 512-aligned panel: those get a 64-row-granular tail launch.
+__global__ __launch_bounds__(64) void k_trsm64_tail(double* __restrict__ A, long ld, const double* __restrict__ L,
+                                                     long ldl) {
+    __shared__ double Ls[64][65];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 64) {
         const int r = idx >> 6, c = idx & 63;
-        base[(long)r * ld + c] = T[r][c];
+        Ls[r][c] = L[r * ldl + c];
+    }
+    double* row = A + ((long)blockIdx.x * 64 + tid) * ld;
+    double x[64];
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+        const d2_t v = *reinterpret_cast<const d2_t*>(row + c);
+        x[c] = v[0];
+        x[c + 1] = v[1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        x[c] = x[c] / Ls[c][c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
+    }
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+        d2_t v;
+        v[0] = x[c];
+        v[1] = x[c + 1];
+        *reinterpret_cast<d2_t*>(row + c) = v;
     }
 }
 
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl) {
     if (nrows <= 0) return;
-    k_trsm64<<<dim3((unsigned)(nrows / 64)), dim3(64), 0, s>>>(A, ld, L, ldl);
+    const int64_t head = nrows % 256;   // rows before the first 256-row boundary of the slab
+    if (head) k_trsm64_tail<<<dim3((unsigned)(head / 64)), dim3(64), 0, s>>>(A, ld, L, ldl);
+    if (nrows - head > 0)
+        k_trsm64<<<dim3((unsigned)((nrows - head) / 256)), dim3(256), 0, s>>>(A + head * ld, ld, L, ldl);
 }
 
 // ---------------------------------------------------------------------------------------
