@@ -123,6 +123,18 @@ int ck_aux_finish(ck_handle* h, double* pred_host, double* pred_err_host);
 /* info flag of the factorisation so far (synchronises). */
 int ck_factor_info(ck_handle* h, int64_t* info);
 
+/* ---- local-neighbourhood cokriging: src/point_prediction.py:45-249 ------------------------- */
+/* Prediction and standard error of process i at pcoords (m x 2) from the observations within
+ * max_dist of each point (cv != 0: observations of process i at distance 0 are withheld,
+ * src/point_prediction.py:141-143).  One workgroup per point: radius search, local covariance,
+ * Cholesky with c and z as extra rows.  Points with no observation in range, or whose local
+ * covariance is not positive definite, get NaN in both outputs (:218-233); their numbers and the
+ * largest neighbourhood size are returned for the caller's warnings.  Needs ck_set_model /
+ * ck_set_data only. */
+int ck_predict_local(ck_handle* h, int i, const double* pcoords_host, int64_t m, double max_dist, int cv,
+                     double* pred_host, double* pred_err_host, int64_t* n_empty, int64_t* n_not_pd,
+                     int64_t* k_max);
+
 /* ---- empirical (cross-)semivariogram / covariogram: src/fields.py:192-232, 378-403 ----- */
 /* Fields i and j: coords (n x 2), residuals = values minus their mean (src/fields.py:380).
  * same != 0: marginal variogram, strict upper triangle of the i-i pairs (:195-199; j args ignored);
@@ -153,7 +165,7 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
- * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin). */
+ * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the Matern correlation through a per-block table of log rho
  * over the squared chord (built on the device from the exact K_nu evaluator and verified against

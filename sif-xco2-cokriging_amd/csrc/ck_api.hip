@@ -821,6 +821,81 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
 }
 
 // ---------------------------------------------------------------------------------------
+// local-neighbourhood cokriging: src/point_prediction.py:45-249
+// ---------------------------------------------------------------------------------------
+extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int64_t m, double max_dist, int cv,
+                                double* pred, double* pred_err, int64_t* n_empty, int64_t* n_not_pd,
+                                int64_t* k_max) {
+    CHKH(h);
+    if (ensure_layout(h)) return -1;
+    if (i < 0 || i >= h->n_procs) return fail("process index out of range");
+    if (m < 0 || (m > 0 && !pcoords)) return fail("bad pcoords");
+    if (n_empty) *n_empty = 0;
+    if (n_not_pd) *n_not_pd = 0;
+    if (k_max) *k_max = 0;
+    if (m == 0) return 0;
+    const int64_t mp = roundup(m, 64);
+    double *d_pc = nullptr, *d_p3 = nullptr, *d_out = nullptr, *d_slab = nullptr;
+    int* d_cnt = nullptr;
+    long long* d_off = nullptr;
+    HIPCHK(hipMalloc((void**)&d_pc, 2 * mp * 8));
+    HIPCHK(hipMalloc((void**)&d_p3, 3 * mp * 8));
+    HIPCHK(hipMalloc((void**)&d_out, 2 * mp * 8));
+    HIPCHK(hipMalloc((void**)&d_cnt, mp * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&d_off, mp * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(d_pc, 0, 2 * mp * 8, h->stream));
+    HIPCHK(hipMemcpyAsync(d_pc, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_prep_sites(h->stream, d_pc, mp, h->metric, d_p3, d_p3 + mp, d_p3 + 2 * mp, nullptr);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    ck_launch_local_count(h->stream, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, layout_of(h), d_cnt);
+    HIPCHK(hipGetLastError());
+    std::vector<int> cnt(m);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // scratch slabs for neighbourhoods beyond the LDS limit
+    const int kl = ck_local_lds_limit();
+    std::vector<long long> off(m, 0);
+    long long tot = 0;
+    int64_t kmx = 0, nempty = 0;
+    for (int64_t p = 0; p < m; ++p) {
+        const long long k = cnt[p];
+        kmx = k > kmx ? k : kmx;
+        if (k == 0) ++nempty;
+        if (k > kl) {
+            off[p] = tot;
+            tot += (k + 2) * k + (k + 1) / 2 + 2;   // matrix + index list (ints), kept 16-byte aligned
+            tot = (tot + 1) & ~1LL;
+        }
+    }
+    if (tot > 0) HIPCHK(hipMalloc((void**)&d_slab, (size_t)tot * 8));
+    HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
+    ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, h->z,
+                          layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(pred, d_out, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pred_err, d_out + mp, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[10] = ms;
+    int64_t npd = 0;
+    for (int64_t p = 0; p < m; ++p)
+        if (cnt[p] > 0 && pred[p] != pred[p]) ++npd;
+    if (n_empty) *n_empty = nempty;
+    if (n_not_pd) *n_not_pd = npd;
+    if (k_max) *k_max = kmx;
+    (void)hipFree(d_pc);
+    (void)hipFree(d_p3);
+    (void)hipFree(d_out);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_off);
+    if (d_slab) (void)hipFree(d_slab);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // empirical (cross-)variogram: src/fields.py:192-232
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {

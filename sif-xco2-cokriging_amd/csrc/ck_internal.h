@@ -85,3 +85,15 @@ void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int cova
                          const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
                          int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
                          unsigned long long* part_cnt, double* sums, long long* counts);
+
+// ---- local-neighbourhood cokriging (ck_local.hip) -------------------------------------------
+// pc: 3 x mpad prediction-site coordinates, sc: 3 x npad site coordinates (exact-formula form)
+void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double max_dist, const double* pc,
+                           int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts);
+// slab_off[p]: offset (doubles) of point p's scratch slab ((k + 2) k doubles + k ints) when its
+// neighbourhood exceeds the LDS limit
+void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
+                           const double* pc, int64_t m, int64_t mpad, const double* sc, const double* z, CkLayout L,
+                           const int* counts, const long long* slab_off, double* slab, double c0var, double* pred,
+                           double* err);
+int ck_local_lds_limit();

@@ -50,6 +50,8 @@ _PROTOS = {
     "ck_panel_apply": [c_void_p, c_int, c_int],
     "ck_aux_finish": [c_void_p, _dp, _dp],
     "ck_factor_info": [c_void_p, POINTER(c_int64)],
+    "ck_predict_local": [c_void_p, c_int, _dp, c_int64, c_double, c_int, _dp, _dp, POINTER(c_int64), POINTER(c_int64),
+                         POINTER(c_int64)],
     "ck_vario_begin": [c_void_p, _dp, _dp, c_int64, _dp, _dp, c_int64, c_int],
     "ck_vario_extent": [c_void_p, c_double, _dp, _dp, POINTER(c_int64)],
     "ck_vario_bin": [c_void_p, c_double, _dp, c_int, c_int, _dp, POINTER(c_int64)],
@@ -270,6 +272,16 @@ class Handle:
         _chk(lib().ck_factor_info(self._h, byref(info)))
         return info.value
 
+    # -- local-neighbourhood prediction ---------------------------------------------------------------
+    def predict_local(self, i, pcoords, max_dist=1e3, cv=False):
+        pc = _f64(pcoords, 2)
+        m = pc.shape[0]
+        pred, err = np.empty(m), np.empty(m)
+        ne, npd, km = c_int64(0), c_int64(0), c_int64(0)
+        _chk(lib().ck_predict_local(self._h, int(i), _p(pc), m, float(max_dist), int(bool(cv)), _p(pred), _p(err),
+                                    byref(ne), byref(npd), byref(km)))
+        return pred, err, dict(n_empty=ne.value, n_not_pd=npd.value, k_max=km.value)
+
     # -- empirical variogram ------------------------------------------------------------------------
     def vario_begin(self, coords_i, resid_i, coords_j=None, resid_j=None):
         ci, ri = _f64(coords_i, 2), _f64(resid_i).ravel()
@@ -328,7 +340,7 @@ class Handle:
         out = np.zeros(12)
         _chk(lib().ck_timings(self._h, _p(out), 12))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
-                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms"]
+                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):

@@ -1,0 +1,79 @@
+"""GPU parity of the local-neighbourhood predictor (ck_predict_local) against fixtures produced by
+the reference's point_prediction.Predictor._predict_chunk (src/point_prediction.py:243-249)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _predictor(tag):
+    from sif_xco2_cokriging_amd import fields, model, point_prediction
+    g = load_golden("point_local")
+    mod = model.MultivariateMatern(params=model.MaternParams().set_values(g[f"params_{tag}"]))
+    mf = fields.MultiField([fields.Field(g["coords0"], g[f"values0_{tag}"]), fields.Field(g["coords1"], g[f"values1_{tag}"])])
+    return point_prediction.Predictor(mod, mf), g
+
+
+@pytest.mark.parametrize("tag", ["A", "R"])
+def test_local_prediction_fixture(tag):
+    P, g = _predictor(tag)
+    n_nan = 0
+    for i in (0, 1):
+        for md in (300, 1000):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                pred, err = P.predict_arrays(i, g[f"pcoords_{tag}"], max_dist=float(md))
+            gp, ge = g[f"pred_{tag}_{i}_{md}"], g[f"pred_err_{tag}_{i}_{md}"]
+            assert np.array_equal(np.isnan(pred), np.isnan(gp))      # empty neighbourhoods -> NaN
+            assert np.array_equal(np.isnan(err), np.isnan(ge))
+            ok = ~np.isnan(gp)
+            n_nan += int((~ok).sum())
+            np.testing.assert_allclose(pred[ok], gp[ok], rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(err[ok] ** 2, ge[ok] ** 2, rtol=1e-8, atol=1e-11)
+    assert n_nan > 0
+
+
+@pytest.mark.parametrize("tag", ["A", "R"])
+def test_local_cross_validation_rule(tag):
+    P, g = _predictor(tag)
+    P.cv = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pred, err = P.predict_arrays(0, g["coords0"][:60], max_dist=700.0)
+    np.testing.assert_allclose(pred, g[f"cv_pred_{tag}"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(err ** 2, g[f"cv_pred_err_{tag}"] ** 2, rtol=1e-8, atol=1e-11)
+
+
+def test_local_large_neighbourhood_matches_joint():
+    """max_dist = infinity makes every neighbourhood the whole data set (k = 400 > the LDS limit,
+    global-scratch path): the local predictor must then equal the joint one."""
+    from sif_xco2_cokriging_amd import native
+    g = load_golden("joint_solve")
+    pv = g["params_A"]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(0)
+    h.set_data(0, g["coords0_A"], g["values0_A"])
+    h.set_data(1, g["coords1_A"], g["values1_A"])
+    pred, err, info = h.predict_local(1, g["pcoords_A"], max_dist=1e9)
+    assert info["k_max"] == 400 and info["n_empty"] == 0 and info["n_not_pd"] == 0
+    ref = g["pred_A_1"]
+    assert np.max(np.abs(pred - ref)) / np.max(np.abs(ref)) < 1e-8
+    assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-9
+
+
+def test_predictor_call_signature_and_warnings():
+    import pandas as pd
+    P, g = _predictor("A")
+    pc = pd.DataFrame(g["pcoords_A"], columns=["lat", "lon"])
+    with pytest.warns(UserWarning, match="No data within maximum distance"):
+        out = P(0, pc, max_dist=300.0, postprocess=False)
+    df = out.to_dataframe().reset_index() if hasattr(out, "to_dataframe") else out.reset_index()
+    assert {"pred", "pred_err"} <= set(df.columns)
+    cv = P.cross_validation(0, max_dist=700.0, postprocess=False)
+    assert list(cv.columns) == ["d1", "d2", "data", "pred", "residual", "pred_err"]
+    assert len(cv) == 200
