@@ -56,11 +56,12 @@ def aux_update_flops(N, m, NB=512):
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (numpy/scipy restatement of the reference path) timed on this host's cores on a
     bounded sample of the same workload: same lattice, same model, same 0.5-degree grid
-    resolution, n = 1 500 per process (N = 3 000) and the first 2 000 grid points."""
+    resolution, n = 3 000 per process (N = 6 000) and the first 4 000 grid points (the full
+    n = 20 000 problem is ~50x the assembly and ~300x the factorisation work of the sample)."""
     import numpy as np
     from oracle import cokrige_oracle as orc
     from sif_xco2_cokriging_amd import synth
-    n, m = 1500, 2000
+    n, m = 3000, 4000
     pb = synth.conus_problem(n, seed=20003)
     p = orc.Params.from_flat(pb["params"])
     t0 = time.perf_counter()
@@ -69,6 +70,18 @@ def cpu_baseline(seconds_budget=25.0):
     return {"value": m / dt, "unit": "grid-points/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle joint_predict, n_obs={n}/process (N={2*n}), m={m} grid points, {dt:.1f} s wall; "
                       f"numpy/scipy with BLAS threads = all {os.cpu_count()} host cores"}
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/):
+    WRITE_SIZE + FETCH_SIZE in separate rocprofv3 --pmc runs, KB -> bytes; null if absent."""
+    p = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("k_syrk_panels_s_bytes_per_launch")
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -173,7 +186,7 @@ def main():
             out["roofline"] = {
                 "kernel": "k_syrk_panels_s (Cholesky trailing update, v_mfma_f64_16x16x4_f64, 128x128 tiles)",
                 "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS, "traffic": measured_traffic(),
                 "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
                 "algorithmic_flops_per_step": flops,
             }

@@ -792,20 +792,26 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 // ---------------------------------------------------------------------------------------
 // X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
 // ---------------------------------------------------------------------------------------
-// 256 threads = 256 rows per workgroup; the 64 x 64 factor sits once in LDS (33 KB) and is read
-// with wave-uniform addresses (broadcast); every lane keeps its row in registers and substitutes
-// right-looking.  Rows go straight between global memory and registers (each lane owns 512
-// contiguous bytes), so LDS holds only L and eight waves fit on a CU.
+// 256 threads = 256 rows per workgroup (the last one may be partial); every lane keeps its row in
+// registers and substitutes right-looking:  x[c] *= 1 / L[c][c];  x[c2] -= x[c] L[c2][c], c2 > c.
+// The factor sits in LDS TRANSPOSED (Lt[c][c2] = L[c2][c]) so the multipliers of one elimination
+// step are contiguous and come in pairs through ds_read_b128 broadcasts; the reciprocals of the
+// diagonal are prepared once per workgroup.  Rows go straight between global memory and
+// registers (each lane owns 512 contiguous bytes).
 // (Feeding L through scalar loads instead of LDS was tried and measured 2x slower.)
-__global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long ld, const double* __restrict__ L,
-                                                    long ldl) {
-    __shared__ double Ls[64][65];
+__global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long ld, long nrows,
+                                                    const double* __restrict__ L, long ldl) {
+    __shared__ __attribute__((aligned(16))) double Lt[64][66];
+    __shared__ double rdiag[64];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
-        Ls[r][c] = L[r * ldl + c];
+        Lt[c][r] = L[r * ldl + c];
     }
-    double* row = A + ((long)blockIdx.x * 256 + tid) * ld;
+    if (tid < 64) rdiag[tid] = 1.0 / L[tid * ldl + tid];
+    const long r = (long)blockIdx.x * 256 + tid;
+    const bool live = r < nrows;
+    double* row = A + (live ? r : 0) * ld;
     double x[64];
 #pragma unroll
     for (int c = 0; c < 64; c += 2) {
@@ -816,59 +822,30 @@ __global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
-        x[c] = x[c] / Ls[c][c];
+        x[c] *= rdiag[c];
+        // multipliers L[c2][c] = Lt[c][c2]: odd leading element, then aligned pairs
+        if (((c + 1) & 1) && c + 1 < 64) x[c + 1] -= x[c] * Lt[c][c + 1];
 #pragma unroll
-        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
+        for (int c2 = (c + 2) & ~1; c2 < 64; c2 += 2) {
+            const d2_t m = *reinterpret_cast<const d2_t*>(&Lt[c][c2]);
+            x[c2] -= x[c] * m[0];
+            x[c2 + 1] -= x[c] * m[1];
+        }
     }
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        d2_t v;
-        v[0] = x[c];
-        v[1] = x[c + 1];
-        *reinterpret_cast<d2_t*>(row + c) = v;
-    }
-}
-
-// nrows % 256 == 0 is guaranteed by the callers except for panel-internal steps, where the
-// slab starts 64 (q + 1) rows into a 512-aligned panel: those get a 64-row-granular tail launch.
-__global__ __launch_bounds__(64) void k_trsm64_tail(double* __restrict__ A, long ld, const double* __restrict__ L,
-                                                     long ldl) {
-    __shared__ double Ls[64][65];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 64) {
-        const int r = idx >> 6, c = idx & 63;
-        Ls[r][c] = L[r * ldl + c];
-    }
-    double* row = A + ((long)blockIdx.x * 64 + tid) * ld;
-    double x[64];
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        const d2_t v = *reinterpret_cast<const d2_t*>(row + c);
-        x[c] = v[0];
-        x[c + 1] = v[1];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        x[c] = x[c] / Ls[c][c];
-#pragma unroll
-        for (int c2 = c + 1; c2 < 64; ++c2) x[c2] -= x[c] * Ls[c2][c];
-    }
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        d2_t v;
-        v[0] = x[c];
-        v[1] = x[c + 1];
-        *reinterpret_cast<d2_t*>(row + c) = v;
+        for (int c = 0; c < 64; c += 2) {
+            d2_t v;
+            v[0] = x[c];
+            v[1] = x[c + 1];
+            *reinterpret_cast<d2_t*>(row + c) = v;
+        }
     }
 }
 
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl) {
     if (nrows <= 0) return;
-    const int64_t head = nrows % 256;   // rows before the first 256-row boundary of the slab
-    if (head) k_trsm64_tail<<<dim3((unsigned)(head / 64)), dim3(64), 0, s>>>(A, ld, L, ldl);
-    if (nrows - head > 0)
-        k_trsm64<<<dim3((unsigned)((nrows - head) / 256)), dim3(256), 0, s>>>(A + head * ld, ld, L, ldl);
+    k_trsm64<<<dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s>>>(A, ld, nrows, L, ldl);
 }
 
 // ---------------------------------------------------------------------------------------
