@@ -104,6 +104,12 @@ int ck_factor(ck_handle* h, int64_t* info);
  * Needs ck_factor; may be called repeatedly. */
 int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host);
 
+/* Leave-one-out cross-validation of process i at all its data sites from ONE factorisation
+ * (Predictor.cross_validation, src/joint_prediction.py:207-257, which re-solves per datum):
+ * pred_q = z_q - (Sigma^-1 z)_q / (Sigma^-1)_qq, pred_err_q = sqrt(1 / (Sigma^-1)_qq); n_i values
+ * each.  Needs ck_factor. */
+int ck_loocv(ck_handle* h, int i, double* pred_host, double* pred_err_host);
+
 /* ---- step-wise form (multi-GPU, fused solve) ------------------------------ */
 int ck_num_panels(ck_handle* h, int* n_panels, int* panel_width, int64_t* n_padded);
 int ck_panel_owner(ck_handle* h, int K, int* owner_rank);

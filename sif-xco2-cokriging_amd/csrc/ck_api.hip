@@ -821,6 +821,47 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
 }
 
 // ---------------------------------------------------------------------------------------
+// leave-one-out cross-validation from ONE factorisation
+// ---------------------------------------------------------------------------------------
+// The reference re-assembles and re-factorises everything once per withheld datum
+// (src/joint_prediction.py:207-257).  Withholding datum q of process i and predicting it from all
+// other data is the Gaussian conditional of z_q given z_-q under N(0, Sigma) -- c0 of that
+// prediction IS the Sigma column of q (nugget only at h == 0, :112-121) and its prior variance IS
+// Sigma_qq -- so
+//     pred_q = z_q - (Sigma^-1 z)_q / (Sigma^-1)_qq,      pred_err_q = sqrt(1 / (Sigma^-1)_qq).
+// With V = L^-1 E_i (unit vectors of the data of process i as right-hand sides) and y = L^-1 z:
+// (Sigma^-1 z)_q = V_q . y and (Sigma^-1)_qq = |V_q|^2: the ordinary forward sweep + reduction.
+extern "C" int ck_loocv(ck_handle* h, int i, double* pred, double* pred_err) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_loocv is the single-process form");
+    if (!h->factored) return fail("ck_factor has not been called");
+    if (i < 0 || i >= h->n_procs) return fail("process index out of range");
+    const int64_t m = h->n[i];
+    if (m <= 0) return 0;
+    // reuse the aux machinery: allocate as for m prediction points (coordinates unused)
+    std::vector<double> dummy(2 * m, 0.0);
+    if (ck_aux_begin(h, i, dummy.data(), m)) return -1;
+    HIPCHK(hipMemsetAsync(h->aux, 0, (size_t)h->mpad * h->Npad * 8, h->stream));
+    ck_launch_loo_rows(h->stream, h->aux, h->mpad, m, i == 0 ? 0 : h->n0p, h->z, h->Npad);
+    HIPCHK(hipGetLastError());
+    for (int K = 0; K < h->nK; ++K)
+        if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, m, m, -1.0, h->d_pred, h->d_err);
+    HIPCHK(hipGetLastError());
+    std::vector<double> s1(m), s2(m);
+    HIPCHK(hipMemcpyAsync(s1.data(), h->d_pred, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(s2.data(), h->d_err, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const double* zi = h->h_values[i].data();
+    for (int64_t q = 0; q < m; ++q) {
+        pred[q] = zi[q] - s1[q] / s2[q];
+        const double e = sqrt(1.0 / s2[q]);
+        pred_err[q] = (e == e) ? e : 0.0;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // local-neighbourhood cokriging: src/point_prediction.py:45-249
 // ---------------------------------------------------------------------------------------
 extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int64_t m, double max_dist, int cv,

@@ -63,8 +63,11 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl);
 // pred[p] = sum_c X[p][c] y[c];  err[p] = nan_to_num(sqrt(c0 - sum_c X[p][c]^2)); X rows live in
 // n_panels panels of width CK_NB at aux + K * mpad * CK_NB; y is row `zrow`.
+// c0 < 0: raw mode, pred[p] = X_p . y and err[p] = |X_p|^2 (leave-one-out).
 void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
                            double c0, double* pred, double* err);
+void ck_launch_loo_rows(hipStream_t s, double* aux, int64_t mpad, int64_t m, int64_t g0, const double* z,
+                        int64_t npad);
 void ck_launch_mfma_probe(hipStream_t s, int32_t* out);
 int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters, double* sink);
 

@@ -876,10 +876,33 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const double* __restrict__ 
         s2 += __shfl_xor(s2, off);
     }
     if (lane == 0) {
-        pred[row] = s1;
-        double e = sqrt(c0 - s2);   // negative variance -> NaN -> 0.0 (np.nan_to_num, joint_prediction.py:78)
-        err[row] = (e == e) ? e : 0.0;
+        if (c0 < 0.0) {             // raw mode (leave-one-out): V_k . y and |V_k|^2
+            pred[row] = s1;
+            err[row] = s2;
+        } else {
+            pred[row] = s1;
+            double e = sqrt(c0 - s2);   // negative variance -> NaN -> 0.0 (np.nan_to_num, joint_prediction.py:78)
+            err[row] = (e == e) ? e : 0.0;
+        }
     }
+}
+
+// right-hand sides of the leave-one-out sweep: row p = unit vector of datum p of the withheld
+// process (internal index g0 + p), row m = the data values z
+__global__ void k_loo_rows(double* __restrict__ aux, long mpad, long m, long g0, const double* __restrict__ z,
+                           long npad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        const long g = g0 + i;
+        aux[(g / CK_NB) * mpad * CK_NB + i * CK_NB + (g % CK_NB)] = 1.0;
+    }
+    if (i < npad) aux[(i / CK_NB) * mpad * CK_NB + m * CK_NB + (i % CK_NB)] = z[i];
+}
+
+void ck_launch_loo_rows(hipStream_t s, double* aux, int64_t mpad, int64_t m, int64_t g0, const double* z,
+                        int64_t npad) {
+    const int64_t n = m > npad ? m : npad;
+    k_loo_rows<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(aux, mpad, m, g0, z, npad);
 }
 
 void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,

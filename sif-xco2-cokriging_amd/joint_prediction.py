@@ -175,17 +175,24 @@ class Predictor:
         ds = out.to_xarray()
         return ds.assign_coords(coords={"time": np.datetime64(self.mf.fields[self.i].timestamp)})
 
-    def cross_validation(self, i: int, postprocess: bool = True) -> pd.DataFrame:
+    def cross_validation(self, i: int, postprocess: bool = True, refactor_each: bool = False) -> pd.DataFrame:
         """Leave-one-out cross-validation at each data location of process ``i``
-        (src/joint_prediction.py:207-257): datum withheld, everything re-solved."""
+        (src/joint_prediction.py:207-257).  The reference withholds one datum and re-assembles
+        and re-factorises everything, n times; here all n leave-one-out predictions come from
+        ONE factorisation (``ck_loocv``: the Gaussian conditional of z_q given the rest,
+        pred_q = z_q - (Sigma^-1 z)_q / (Sigma^-1)_qq, var_q = 1 / (Sigma^-1)_qq -- the same
+        numbers).  ``refactor_each=True`` runs the reference's n-solve loop instead."""
         names = ["lat", "lon"] if postprocess else ["d1", "d2"]
         f = self.mf.fields[i]
         data = pd.DataFrame(np.hstack((f.coords_main, np.atleast_2d(f.values_main).T)), columns=names + ["data"])
-        pred = np.empty(len(data))
-        err = np.empty(len(data))
-        for ix in range(len(data)):
-            p, e = self.predict_arrays(i, f.coords_main[ix], cv_ix=ix)
-            pred[ix], err[ix] = p[0], e[0]
+        if refactor_each:
+            pred = np.empty(len(data))
+            err = np.empty(len(data))
+            for ix in range(len(data)):
+                p, e = self.predict_arrays(i, f.coords_main[ix], cv_ix=ix)
+                pred[ix], err[ix] = p[0], e[0]
+        else:
+            pred, err = self._factored_handle().loocv(i, len(data))
         if postprocess:
             at = f.ds.attrs
             tmp = pd.DataFrame({"lat": data["lat"], "lon": data["lon"], "pred": pred, "pred_err": err})

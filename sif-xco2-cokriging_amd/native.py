@@ -42,6 +42,7 @@ _PROTOS = {
     "ck_assemble_joint": [c_void_p],
     "ck_factor": [c_void_p, POINTER(c_int64)],
     "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
+    "ck_loocv": [c_void_p, c_int, _dp, _dp],
     "ck_num_panels": [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
     "ck_panel_owner": [c_void_p, c_int, POINTER(c_int)],
     "ck_aux_begin": [c_void_p, c_int, _dp, c_int64],
@@ -233,6 +234,11 @@ class Handle:
         m = pc.shape[0]
         pred, err = np.empty(m), np.empty(m)
         _chk(lib().ck_predict(self._h, int(i), _p(pc), m, _p(pred), _p(err)))
+        return pred, err
+
+    def loocv(self, i, n_i):
+        pred, err = np.empty(n_i), np.empty(n_i)
+        _chk(lib().ck_loocv(self._h, int(i), _p(pred), _p(err)))
         return pred, err
 
     # -- step-wise form -----------------------------------------------------------------------

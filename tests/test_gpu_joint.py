@@ -239,13 +239,16 @@ def test_predictor_class_api(native):
     assert str(e.value) == str(g2["message"])
 
 
-def test_joint_loocv(native):
+@pytest.mark.parametrize("refactor_each", [False, True])
+def test_joint_loocv(native, refactor_each):
+    """leave-one-out: from one factorisation (ck_loocv) and by the reference's n-solve loop"""
     from sif_xco2_cokriging_amd import fields, joint_prediction, model
     g = load_golden("joint_loocv")
     mod = model.MultivariateMatern(params=model.MaternParams().set_values(g["params"]))
     mf = fields.MultiField([fields.Field(g["coords0"], g["values0"]), fields.Field(g["coords1"], g["values1"])])
     P = joint_prediction.Predictor(mod, mf)
-    df = P.cross_validation(0, postprocess=False)
-    assert rel(df["pred"].values, g["pred_0"]) < 1e-9
-    assert rel(df["pred_err"].values, g["pred_err_0"]) < 1e-9
-    np.testing.assert_allclose(df["residual"].values, g["values0"] - g["pred_0"], rtol=1e-7, atol=1e-9)
+    for i in (0, 1):
+        df = P.cross_validation(i, postprocess=False, refactor_each=refactor_each)
+        assert rel(df["pred"].values, g[f"pred_{i}"]) < 1e-9
+        assert rel(df["pred_err"].values, g[f"pred_err_{i}"]) < 1e-9
+        np.testing.assert_allclose(df["residual"].values, g[f"values{i}"] - g[f"pred_{i}"], rtol=1e-7, atol=1e-9)
