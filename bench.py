@@ -103,11 +103,19 @@ def main():
     import numpy as np
     import torch
     from sif_xco2_cokriging_amd import native, synth
+    # one rank per GPU; CK_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of
+    # the multi-rank path (RCCL refuses two ranks on one device)
+    backend = os.environ.get("CK_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     params = synth.SET_A if args.params == "A" else synth.SET_B
     pb = synth.conus_problem(args.n_obs, seed=20003, params=params)
