@@ -110,6 +110,11 @@ int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, doubl
  * each.  Needs ck_factor. */
 int ck_loocv(ck_handle* h, int i, double* pred_host, double* pred_err_host);
 
+/* Simulation draw z = L eps in the caller's stacked order (process 0 sites, then process 1):
+ * sim.BivariateRandomField._simulate (src/sim.py:52-54: cholesky(cmat, lower=True) @ noise).
+ * n = number of observations; needs ck_factor. */
+int ck_sample(ck_handle* h, const double* noise_host, double* out_host, int64_t n);
+
 /* ---- step-wise form (multi-GPU, fused solve) ------------------------------ */
 int ck_num_panels(ck_handle* h, int* n_panels, int* panel_width, int64_t* n_padded);
 int ck_panel_owner(ck_handle* h, int K, int* owner_rank);

@@ -821,6 +821,33 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
 }
 
 // ---------------------------------------------------------------------------------------
+// simulation draw z = L eps  (sim.BivariateRandomField._simulate, src/sim.py:52-54)
+// ---------------------------------------------------------------------------------------
+extern "C" int ck_sample(ck_handle* h, const double* noise, double* out, int64_t n) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_sample is the single-process form");
+    if (!h->factored) return fail("ck_factor has not been called");
+    if (n != h->N) return fail("n must equal the number of observations");
+    const int64_t Np = h->Npad, n0 = h->n[0], gap = h->n0p - n0;
+    std::vector<double> hv(Np, 0.0), ho(Np);
+    memcpy(hv.data(), noise, n0 * 8);
+    if (n > n0) memcpy(hv.data() + h->n0p, noise + n0, (n - n0) * 8);
+    double *dv = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void**)&dv, Np * 8));
+    HIPCHK(hipMalloc((void**)&dout, Np * 8));
+    HIPCHK(hipMemcpyAsync(dv, hv.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_tri_matvec(h->stream, h->d_sigptr, Np, dv, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ho.data(), dout, Np * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(out, ho.data(), n0 * 8);
+    if (n > n0) memcpy(out + n0, ho.data() + n0 + gap, (n - n0) * 8);
+    (void)hipFree(dv);
+    (void)hipFree(dout);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // leave-one-out cross-validation from ONE factorisation
 // ---------------------------------------------------------------------------------------
 // The reference re-assembles and re-factorises everything once per withheld datum

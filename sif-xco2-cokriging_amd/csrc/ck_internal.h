@@ -66,6 +66,7 @@ void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const
 // c0 < 0: raw mode, pred[p] = X_p . y and err[p] = |X_p|^2 (leave-one-out).
 void ck_launch_reduce_pred(hipStream_t s, const double* aux, int64_t mpad, int n_panels, int64_t m, int64_t zrow,
                            double c0, double* pred, double* err);
+void ck_launch_tri_matvec(hipStream_t s, double* const* sigptr_dev, int64_t npad, const double* v, double* out);
 void ck_launch_loo_rows(hipStream_t s, double* aux, int64_t mpad, int64_t m, int64_t g0, const double* z,
                         int64_t npad);
 void ck_launch_mfma_probe(hipStream_t s, int32_t* out);

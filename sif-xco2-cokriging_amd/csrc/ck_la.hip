@@ -899,6 +899,29 @@ __global__ void k_loo_rows(double* __restrict__ aux, long mpad, long m, long g0,
     if (i < npad) aux[(i / CK_NB) * mpad * CK_NB + m * CK_NB + (i % CK_NB)] = z[i];
 }
 
+// out[r] = sum_{c <= r} L[r][c] v[c] over the packed panels (simulation draw z = L eps, src/sim.py:52-54)
+__global__ __launch_bounds__(256) void k_tri_matvec(double* const* __restrict__ sigptr, long npad,
+                                                     const double* __restrict__ v, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= npad) return;
+    const int Kr = (int)(r / CK_NB);
+    double s = 0.0;
+    for (int K = 0; K <= Kr; ++K) {
+        const double* row = sigptr[K] + (r - (long)K * CK_NB) * CK_NB;
+        const long cmax = (K == Kr) ? (r - (long)K * CK_NB) : (CK_NB - 1);
+        const double* vk = v + (long)K * CK_NB;
+        for (long c = lane; c <= cmax; c += 64) s += row[c] * vk[c];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[r] = s;
+}
+
+void ck_launch_tri_matvec(hipStream_t s, double* const* sigptr_dev, int64_t npad, const double* v, double* out) {
+    k_tri_matvec<<<dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s>>>(sigptr_dev, npad, v, out);
+}
+
 void ck_launch_loo_rows(hipStream_t s, double* aux, int64_t mpad, int64_t m, int64_t g0, const double* z,
                         int64_t npad) {
     const int64_t n = m > npad ? m : npad;

@@ -43,6 +43,7 @@ _PROTOS = {
     "ck_factor": [c_void_p, POINTER(c_int64)],
     "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
     "ck_loocv": [c_void_p, c_int, _dp, _dp],
+    "ck_sample": [c_void_p, _dp, _dp, c_int64],
     "ck_num_panels": [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
     "ck_panel_owner": [c_void_p, c_int, POINTER(c_int)],
     "ck_aux_begin": [c_void_p, c_int, _dp, c_int64],
@@ -240,6 +241,12 @@ class Handle:
         pred, err = np.empty(n_i), np.empty(n_i)
         _chk(lib().ck_loocv(self._h, int(i), _p(pred), _p(err)))
         return pred, err
+
+    def sample(self, noise):
+        e = _f64(noise).ravel()
+        out = np.empty(e.size)
+        _chk(lib().ck_sample(self._h, _p(e), _p(out), e.size))
+        return out
 
     # -- step-wise form -----------------------------------------------------------------------
     def num_panels(self):

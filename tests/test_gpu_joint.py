@@ -252,3 +252,31 @@ def test_joint_loocv(native, refactor_each):
         assert rel(df["pred"].values, g[f"pred_{i}"]) < 1e-9
         assert rel(df["pred_err"].values, g[f"pred_err_{i}"]) < 1e-9
         np.testing.assert_allclose(df["residual"].values, g[f"values{i}"] - g[f"pred_{i}"], rtol=1e-7, atol=1e-9)
+
+
+def test_sim_field_draw(native):
+    """sim.BivariateRandomField: cmat assembly + Cholesky + L @ noise against the reference's draw
+    (fixture from src/sim.py on a 13 x 11 grid, seed 7)."""
+    from sif_xco2_cokriging_amd import model, sim
+    g = load_golden("sim_field")
+    grid = sim.CartesianGrid(xcount=13, ycount=11)
+    np.testing.assert_allclose(grid.coords.values, g["coords"], rtol=0, atol=0)
+    mod = model.MultivariateMatern(params=model.MaternParams().set_values(g["params"]))
+    rf = sim.BivariateRandomField(mod, grid, seed=7)
+    np.testing.assert_allclose(rf.fields[0]["value"].values, g["field0"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(rf.fields[1]["value"].values, g["field1"], rtol=1e-7, atol=1e-9)
+    samples = rf.sample(size=40, epsilon=0.1)
+    mf = rf.to_fields(samples)
+    assert mf.n_procs == 2 and mf.fields[0].size == 40 and mf.fields[1].size == 40
+    # co-located half: the first ceil(40/2) sampled sites are shared by the two processes
+    a = {tuple(r) for r in mf.fields[0].coords}
+    b = {tuple(r) for r in mf.fields[1].coords}
+    assert len(a & b) == 20
+
+
+def test_predict_zero_points(native):
+    g = load_golden("joint_loocv")
+    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [g["values0"], g["values1"]], HAV)
+    assert h.factor() == 0
+    pred, err = h.predict(0, np.zeros((0, 2)))
+    assert pred.shape == (0,) and err.shape == (0,)
