@@ -280,3 +280,22 @@ def test_predict_zero_points(native):
     assert h.factor() == 0
     pred, err = h.predict(0, np.zeros((0, 2)))
     assert pred.shape == (0,) and err.shape == (0,)
+
+
+def test_notebook_flow_end_to_end(native):
+    """The reference's simulation_experiment notebook, every step on the GPU (simulate -> sample ->
+    cokrige), against the digits the notebook records (research/simulation_experiment.ipynb:762-763)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ck_example_simexp", os.path.join(root, "examples", "simulation_experiment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pred, err = mod.run()
+    assert pred.shape == (2601,)
+    assert np.allclose(pred[:4], [1.025, 1.129, 1.177, 1.106], atol=6e-4)
+    assert np.allclose(pred[-3:], [-0.3236, -0.2804, -0.2439], atol=6e-5)
+    assert np.allclose(err[:4], [0.2072, 0.1824, 0.1494, 0.0871], atol=6e-5)
+    assert np.allclose(err[-3:], [0.6993, 0.7249, 0.754], atol=6e-4)
+    g = load_golden("kat_simulation_experiment")
+    assert rel(pred, g["pred"]) < 1e-5
