@@ -184,8 +184,8 @@ int ck_timings(ck_handle* h, double* out, int n);
  * its check (else that block uses the exact evaluator), its size / range, its measured error. */
 int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, double* q_lo, double* q_hi,
                   double* max_rel_err);
-/* Entries the table path handed to the exact evaluator (pairs closer than the table's lower end
- * or beyond its upper end) since the last reset, over all handles of this process. */
+/* Entries the table path deferred to the exact evaluator (pairs closer than the table's lower end
+ * or beyond its upper end) in this handle's assemblies since the last reset. */
 int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events;
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;

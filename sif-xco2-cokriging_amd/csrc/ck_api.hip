@@ -77,8 +77,12 @@ struct ck_handle {
     double** d_coefptr = nullptr;
     bool tables_built = false;
     bool exact_cov = false;             // option "exact_cov": bypass the tables
+    CkWorklist wl = {nullptr, nullptr, 0};   // entries deferred by the table kernels
+    int64_t fallback_total = 0;
     std::vector<double*> sig;    // per panel; nullptr if not owned
     double** d_sigptr = nullptr;
+    int *d_tile0 = nullptr, *d_panel_of = nullptr;   // assembly launch map of the owned panels
+    int n_owned = 0, total_tiles = 0;
     double* recv[2] = {nullptr, nullptr};   // receive buffers for remote panels (world > 1)
     long long* d_info = nullptr;
     bool assembled = false, factored = false;
@@ -182,6 +186,10 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (void* p : h->owned) (void)hipFree(p);
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_info);
+    if (h->d_tile0) (void)hipFree(h->d_tile0);
+    if (h->d_panel_of) (void)hipFree(h->d_panel_of);
+    if (h->wl.items) (void)hipFree(h->wl.items);
+    if (h->wl.count) (void)hipFree(h->wl.count);
     if (h->d_tabs) (void)hipFree(h->d_tabs);
     if (h->d_coefptr) (void)hipFree(h->d_coefptr);
     for (int b = 0; b < 3; ++b)
@@ -284,6 +292,12 @@ static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------
 static int build_tables(ck_handle* h, double qbox_euclid) {
     const int nblk = h->n_procs == 1 ? 1 : 3;
+    if (!h->wl.items) {
+        h->wl.cap = 1u << 22;   // 4 M deferred entries (32 MB); beyond that the assembly re-runs exactly
+        HIPCHK(hipMalloc((void**)&h->wl.items, (size_t)h->wl.cap * sizeof(int2)));
+        HIPCHK(hipMalloc((void**)&h->wl.count, sizeof(unsigned)));
+        HIPCHK(hipMemset(h->wl.count, 0, sizeof(unsigned)));
+    }
     const int ND = CK_TAB_DEG + 1;
     if (!h->d_tabs) {
         HIPCHK(hipMalloc((void**)&h->d_tabs, 3 * sizeof(CkTable)));
@@ -407,6 +421,20 @@ static int ensure_layout(ck_handle* h) {
         }
         if (dev_alloc(h, (void**)&h->d_sigptr, (int64_t)h->nK * sizeof(double*))) return -1;
         HIPCHK(hipMemcpy(h->d_sigptr, h->sig.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
+        std::vector<int> tile0, panel_of;
+        int acc = 0;
+        for (int K = h->rank; K < h->nK; K += h->world) {
+            tile0.push_back(acc);
+            panel_of.push_back(K);
+            acc += (int)((Np - (int64_t)K * CK_NB) / 64);
+        }
+        tile0.push_back(acc);
+        h->n_owned = (int)panel_of.size();
+        h->total_tiles = acc;
+        HIPCHK(hipMalloc((void**)&h->d_tile0, tile0.size() * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_panel_of, (panel_of.size() + 1) * sizeof(int)));
+        HIPCHK(hipMemcpy(h->d_tile0, tile0.data(), tile0.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_panel_of, panel_of.data(), panel_of.size() * sizeof(int), hipMemcpyHostToDevice));
         if (h->world > 1) {
             for (int b = 0; b < 2; ++b)
                 if (dev_alloc(h, (void**)&h->recv[b], Np * CK_NB * 8)) return -1;
@@ -501,10 +529,22 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int K = h->rank; K < h->nK; K += h->world) {
-        const int64_t row0 = (int64_t)K * CK_NB;
-        ck_launch_assemble_sigma_panel(h->stream, tables_usable(h), h->d_blk, h->d_tabs, h->d_coefptr, h->metric,
-                                       h->s0, h->su, layout_of(h), row0, h->Npad - row0, row0, h->sig[K]);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fast = tables_usable(h) && attempt == 0;
+        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        {
+            CkPanelMap pm{h->d_tile0, h->d_panel_of, h->d_sigptr, h->n_owned, nullptr, 0};
+            ck_launch_assemble_sigma(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0, h->su,
+                                     layout_of(h), pm, h->total_tiles, h->wl);
+        }
+        if (!fast) break;
+        ck_launch_assemble_fix(h->stream, false, h->d_blk, h->metric, 0, nullptr, 0, h->s0, layout_of(h), h->wl,
+                               h->d_sigptr, nullptr);
+        unsigned cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, h->wl.count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->fallback_total += cnt;
+        if (cnt <= h->wl.cap) break;   // else: too many out-of-table pairs for the list -> exact kernels
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(long long), h->stream));
@@ -748,10 +788,20 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
     HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
     if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
-    for (int K = 0; K < h->nK; ++K)
-        ck_launch_assemble_aux_panel(h->stream, tables_usable(h), h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i,
-                                     h->p0, h->pu, m, mpad, h->s0, h->su, h->z, layout_of(h), (int64_t)K * CK_NB,
-                                     h->aux + (int64_t)K * mpad * CK_NB);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fast = tables_usable(h) && attempt == 0;
+        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        ck_launch_assemble_aux(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i, h->p0, h->pu, m,
+                               mpad, h->s0, h->su, h->z, layout_of(h), h->nK, h->aux, h->wl);
+        if (!fast) break;
+        ck_launch_assemble_fix(h->stream, true, h->d_blk, h->metric, i, h->p0, mpad, h->s0, layout_of(h), h->wl,
+                               h->d_sigptr, h->aux);
+        unsigned cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, h->wl.count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->fallback_total += cnt;
+        if (cnt <= h->wl.cap) break;
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));   // pcoords is caller memory: do not return before the copy is done
@@ -1256,10 +1306,8 @@ extern "C" int ck_table_info(ck_handle* h, int block, int* enabled, int* n_inter
 
 extern "C" int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count) {
     CHKH(h);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    unsigned long long v = 0;
-    if (ck_fallback_counter(h->stream, reset, &v)) return fail("cannot read the fallback counter");
-    if (count) *count = (int64_t)v;
+    if (count) *count = h->fallback_total;
+    if (reset) h->fallback_total = 0;
     return 0;
 }
 

@@ -82,44 +82,97 @@ __device__ __noinline__ double exact_entry_call(const CkMatern* m, int metric, i
     return ck_cov_entry(*m, pair_dist(metric, ac0, ac1, ac2, bc0, bc1, bc2), nug);
 }
 
-// number of entries the table path handed to the exact formulas since the last reset (diagnostic)
-__device__ unsigned long long g_ck_fallback_entries = 0;
+// exp(p) for p <= 0 (log rho is never positive): no overflow handling, underflow through ldexp
+__device__ __forceinline__ double ck_exp_nonpos(double p) {
+    const double n = rint(p * 1.4426950408889634074);                 // p / ln 2
+    double r = fma(n, -6.93147180369123816490e-01, p);               // ln 2 hi
+    r = fma(n, -1.90821492927058770002e-10, r);                      // ln 2 lo
+    double e = 2.50521083854417187751e-08;                           // 1/11!
+    e = fma(e, r, 2.75573192239858906526e-07);
+    e = fma(e, r, 2.75573192239858906526e-06);
+    e = fma(e, r, 2.48015873015873015873e-05);
+    e = fma(e, r, 1.98412698412698412698e-04);
+    e = fma(e, r, 1.38888888888888888889e-03);
+    e = fma(e, r, 8.33333333333333333333e-03);
+    e = fma(e, r, 4.16666666666666666667e-02);
+    e = fma(e, r, 1.66666666666666666667e-01);
+    e = fma(e, r, 0.5);
+    e = fma(e, r, 1.0);
+    e = fma(e, r, 1.0);
+    return ldexp(e, (int)n);
+}
 
-// One entry through the table.  The exact-formula call sits behind a WAVE-UNIFORM test (ballot):
-// hipcc does not reliably skip a short divergent block that holds a call.
-__device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, int metric,
-                                             int nug, double ac0, double ac1, double ac2, double au0, double au1,
-                                             double au2, double bc0, double bc1, double bc2, double bu0, double bu1,
-                                             double bu2, bool valid) {
+// One entry through the table.  Pairs outside the table's range (closer than its lower end, or
+// beyond its upper end) are NOT evaluated here: the caller collects them in a per-thread bit mask
+// and appends their (row, col) to a worklist that k_assemble_fix evaluates with the exact formulas
+// afterwards.  Keeping the Bessel code out of this kernel halves its register count.
+__device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, double ac0,
+                                             double ac1, double au0, double au1, double au2, double bc0, double bc1,
+                                             double bu0, double bu1, double bu2, int nug, bool valid, bool* slow) {
     const bool same = (ac0 == bc0 && ac1 == bc1);   // h == 0 exactly (model.py:195-196)
     const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
     const double q = dx * dx + dy * dy + dz * dz;
     const bool in_tab = (q >= tab.q_lo && q < tab.q_hi);
     int iv;
     const double x = ck_table_x(in_tab ? q : tab.q_lo, &iv, tab.base);   // keep the lookup in range
-    double val = m.amp * exp(ck_table_logrho(lcoef, tab.n_int, iv, x));
+    double val = m.amp * ck_exp_nonpos(ck_table_logrho(lcoef, tab.n_int, iv, x));
     if (same) val = nug ? m.amp + m.nugget : m.amp;
-    const bool slow = valid && !same && !in_tab;   // padding lanes never ask for the exact formulas
-    const unsigned long long sl = __builtin_amdgcn_ballot_w64(slow);
-    if (sl != 0ULL) {
-        if (slow) val = exact_entry_call(&m, metric, nug, ac0, ac1, ac2, bc0, bc1, bc2);
-        if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(sl))
-            atomicAdd(&g_ck_fallback_entries, (unsigned long long)__builtin_popcountll(sl));
-    }
+    *slow = valid && !same && !in_tab;              // padding lanes never ask for the exact formulas
     return val;
+}
+
+// append this thread's deferred entries (bit k of `mask` = entry k of the sub-tile) to the worklist
+__device__ __noinline__ void worklist_append(const CkWorklist& wl, unsigned mask, int r0, int rstride, int c0) {
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < 16; ++k) {
+        const bool f = (mask >> k) & 1u;
+        const unsigned long long sl = __builtin_amdgcn_ballot_w64(f);
+        if (sl == 0ULL) continue;
+        const int leader = __builtin_ctzll(sl);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(wl.count, (unsigned)__builtin_popcountll(sl));
+        base = __shfl(base, leader);
+        if (f) {
+            const unsigned slot = base + (unsigned)__builtin_popcountll(sl & ((1ULL << lane) - 1ULL));
+            // entry k = (b, a, e): column 32 b + e, row a * rstride
+            const int b = k >> 3, a = (k >> 1) & 3, e = k & 1;
+            if (slot < wl.cap) wl.items[slot] = make_int2(r0 + a * rstride, c0 + 32 * b + e);
+        }
+    }
 }
 
 // FAST: table path (every block's table enabled) | exact per-entry Bessel evaluation.
 // AUX:  rows are prediction sites (row m = data values z, rows > m zero) | rows are data sites.
 template <bool FAST, bool AUX>
-__global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ blk, const CkTable* __restrict__ tabs,
-                                                   const double* const* __restrict__ coefs, int metric, int i_pred,
-                                                   CkSiteRef R, long m, CkSiteRef S, const double* __restrict__ z,
-                                                   CkLayout L, long row0, long col0, double* __restrict__ out) {
+__global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* __restrict__ blk,
+                                                                 const CkTable* __restrict__ tabs,
+                                                                 const double* const* __restrict__ coefs, int metric,
+                                                                 int i_pred, CkSiteRef R, long m, CkSiteRef S,
+                                                                 const double* __restrict__ z, CkLayout L,
+                                                                 CkPanelMap pm, CkWorklist wl) {
     __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_MAXINT : 1];
     __shared__ CkTable ltab;
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    const long rt = row0 + (long)blockIdx.y * 64;
+    // blockIdx.x enumerates the 64-row tiles of ALL panels of this launch; a workgroup walks the
+    // eight 64 x 64 sub-tiles of its 64 x 512 strip
+    long row0, col0;
+    double* out;
+    long tile;
+    if (AUX) {   // every panel has mpad / 64 row tiles
+        const long j = blockIdx.x / pm.aux_tiles;
+        tile = blockIdx.x - j * pm.aux_tiles;
+        row0 = 0;
+        col0 = j * CK_NB;
+        out = pm.aux + j * pm.aux_tiles * 64 * CK_NB;
+    } else {     // owned panels, sizes differ: tile0[j] = first tile of the j-th owned panel
+        int j = 0;
+        while (j + 1 < pm.n_panels && pm.tile0[j + 1] <= (int)blockIdx.x) ++j;
+        const int K = pm.panel_of[j];
+        tile = blockIdx.x - pm.tile0[j];
+        row0 = col0 = (long)K * CK_NB;
+        out = pm.sigptr[K];
+    }
+    const long rt = row0 + tile * 64;
     const int pr = AUX ? i_pred : (int)(rt >= L.n0p);
     // this thread's four rows
     double rc0[4], rc1[4], rc2[4], ru0[4], ru1[4], ru2[4];
@@ -130,7 +183,7 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
         rv[a] = AUX ? (r < m) : site_valid(L, r);
         rc0[a] = R.c0[r];
         rc1[a] = R.c1[r];
-        rc2[a] = R.c2[r];
+        rc2[a] = FAST ? 0.0 : R.c2[r];
         if (FAST) {
             ru0[a] = R.u0[r];
             ru1[a] = R.u1[r];
@@ -138,8 +191,9 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
         }
     }
     int loaded = -1;
-    for (int sub = 0; sub < 4; ++sub) {
-        const long ct = col0 + (long)blockIdx.x * 256 + sub * 64;
+    for (int sub = 0; sub < CK_NB / 64; ++sub) {   // the whole panel width: one table load per 256 KB of output
+        unsigned slowmask = 0;
+        const long ct = col0 + sub * 64;
         const int pc = (int)(ct >= L.n0p);
         const int bidx = pr + pc;
         const int nug = (pr == pc);
@@ -164,7 +218,7 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
                 cv[e] = site_valid(L, c + e);
                 cc0[e] = S.c0[c + e];
                 cc1[e] = S.c1[c + e];
-                cc2[e] = S.c2[c + e];
+                cc2[e] = FAST ? 0.0 : S.c2[c + e];
                 if (FAST) {
                     cu0[e] = S.u0[c + e];
                     cu1[e] = S.u1[c + e];
@@ -181,8 +235,10 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
                     double val = 0.0;
                     const bool valid = rv[a] && cv[e];
                     if (FAST) {
-                        val = fast_entry(mb, ltab, lcoef, metric, nug, rc0[a], rc1[a], rc2[a], ru0[a], ru1[a], ru2[a],
-                                         cc0[e], cc1[e], cc2[e], cu0[e], cu1[e], cu2[e], valid);
+                        bool slow;
+                        val = fast_entry(mb, ltab, lcoef, rc0[a], rc1[a], ru0[a], ru1[a], ru2[a], cc0[e], cc1[e],
+                                         cu0[e], cu1[e], cu2[e], nug, valid, &slow);
+                        slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
                     } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
                         if (valid)
                             val = exact_entry_call(&mb, metric, nug, rc0[a], rc1[a], rc2[a], cc0[e], cc1[e], cc2[e]);
@@ -199,39 +255,77 @@ __global__ __launch_bounds__(256) void k_assemble(const CkMatern* __restrict__ b
                 *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
             }
         }
+        if (FAST && __builtin_amdgcn_ballot_w64(slowmask != 0u) != 0ULL)   // rare: hand the pairs to the exact pass
+            worklist_append(wl, slowmask, (int)(rt + ty), 16, (int)(ct + 2 * tx));
     }
 }
 
-void ck_launch_assemble_sigma_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                                    const double* const* coefs, int metric, const double* c, const double* u,
-                                    CkLayout L, int64_t row0, int64_t nrows, int64_t col0, double* out) {
-    if (nrows <= 0) return;
-    const int64_t np = L.npad;
-    CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
-    dim3 grid(CK_NB / 256, (unsigned)(nrows / 64));
-    if (fast)
-        k_assemble<true, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, row0,
-                                                           col0, out);
-    else
-        k_assemble<false, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, row0,
-                                                            col0, out);
+// Exact evaluation of the worklist entries (see fast_entry).  Sigma: entry (r, c) lives in panel
+// K = c / NB at sigptr[K] + (r - K NB) NB + (c - K NB); right-hand sides: aux + K mpad NB + r NB + ...
+template <bool AUX>
+__global__ __launch_bounds__(256) void k_assemble_fix(const CkMatern* __restrict__ blk, int metric, int i_pred,
+                                                       CkSiteRef R, CkSiteRef S, CkLayout L, CkWorklist wl,
+                                                       double* const* __restrict__ sigptr, double* __restrict__ aux,
+                                                       long mpad) {
+    const unsigned n = *wl.count < wl.cap ? *wl.count : wl.cap;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int2 it = wl.items[e];
+        const long r = it.x, c = it.y;
+        const int pc = c >= L.n0p;
+        const int pr = AUX ? i_pred : (int)(r >= L.n0p);
+        const double val = ck_cov_entry(blk[pr + pc], pair_dist(metric, R.c0[r], R.c1[r], R.c2[r], S.c0[c], S.c1[c], S.c2[c]),
+                                        pr == pc);
+        const long K = c / CK_NB;
+        if (AUX)
+            aux[K * mpad * CK_NB + r * CK_NB + (c - K * CK_NB)] = val;
+        else
+            sigptr[K][(r - K * CK_NB) * CK_NB + (c - K * CK_NB)] = val;
+    }
 }
 
-void ck_launch_assemble_aux_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                                  const double* const* coefs, int metric, int i_pred, const double* pc,
-                                  const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
-                                  const double* z, CkLayout L, int64_t col0, double* out) {
-    if (mpad <= 0) return;
+// all owned Sigma panels in one launch
+void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                              const double* const* coefs, int metric, const double* c, const double* u, CkLayout L,
+                              CkPanelMap pm, int total_tiles, CkWorklist wl) {
+    if (total_tiles <= 0) return;
+    const int64_t np = L.npad;
+    CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
+    dim3 grid((unsigned)total_tiles);
+    if (fast)
+        k_assemble<true, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, pm, wl);
+    else
+        k_assemble<false, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, pm, wl);
+}
+
+// all right-hand-side panels in one launch
+void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                            const double* const* coefs, int metric, int i_pred, const double* pc, const double* pu,
+                            int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
+                            int n_panels, double* aux, CkWorklist wl) {
+    if (mpad <= 0 || n_panels <= 0) return;
     const int64_t np = L.npad;
     CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, pu, pu + mpad, pu + 2 * mpad};
     CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
-    dim3 grid(CK_NB / 256, (unsigned)(mpad / 64));
+    CkPanelMap pm{nullptr, nullptr, nullptr, n_panels, aux, (long)(mpad / 64)};
+    dim3 grid((unsigned)(n_panels * (mpad / 64)));
     if (fast)
-        k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, 0, col0,
-                                                          out);
+        k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl);
     else
-        k_assemble<false, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, 0, col0,
-                                                           out);
+        k_assemble<false, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl);
+}
+
+// after all table-path panels of one assembly: evaluate what they deferred
+void ck_launch_assemble_fix(hipStream_t s, bool aux_rows, const CkMatern* blk, int metric, int i_pred,
+                            const double* pc, int64_t mpad, const double* c, CkLayout L, CkWorklist wl,
+                            double* const* sigptr, double* aux) {
+    const int64_t np = L.npad;
+    CkSiteRef S{c, c + np, c + 2 * np, nullptr, nullptr, nullptr};
+    if (aux_rows) {
+        CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, nullptr, nullptr, nullptr};
+        k_assemble_fix<true><<<dim3(256), dim3(256), 0, s>>>(blk, metric, i_pred, P, S, L, wl, sigptr, aux, mpad);
+    } else {
+        k_assemble_fix<false><<<dim3(256), dim3(256), 0, s>>>(blk, metric, i_pred, S, S, L, wl, sigptr, aux, mpad);
+    }
 }
 
 // dense a x b block (element-wise parity surface) ------------------------------------------
@@ -314,15 +408,4 @@ void ck_launch_table_check(hipStream_t s, const CkMatern* m, int metric, CkTable
     const int n = tab.n_int * 8;
     if (n <= 0) return;
     k_table_check<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(m, metric, tab, coef, max_err_bits);
-}
-
-int ck_fallback_counter(hipStream_t s, int reset, unsigned long long* out) {
-    unsigned long long v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ck_fallback_entries), 8) != hipSuccess) return -1;
-    if (out) *out = v;
-    if (reset) {
-        v = 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ck_fallback_entries), &v, 8) != hipSuccess) return -1;
-    }
-    return 0;
 }

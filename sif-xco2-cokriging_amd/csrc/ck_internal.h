@@ -19,23 +19,43 @@ void ck_launch_prep_sites(hipStream_t s, const double* coords, int64_t n, int me
 void ck_launch_table_nodes(hipStream_t s, const CkMatern* m, int metric, const double* q, int64_t n, double* out);
 void ck_launch_table_check(hipStream_t s, const CkMatern* m, int metric, CkTable tab, const double* coef,
                            unsigned long long* max_err_bits);
-int ck_fallback_counter(hipStream_t s, int reset, unsigned long long* out);
 // Internal site order: process 0 in [0, n0), process 1 in [n0p, nend), n0p = roundup(n0, 64);
 // every other index below npad is padding (identity in Sigma, zero in the right-hand sides).
 struct CkLayout {
     long n0, n0p, nend, npad;
 };
-// One block column of Sigma: rows [row0, row0 + nrows) x cols [col0, col0 + CK_NB), ld = CK_NB.
+// entries the table kernels defer to the exact evaluator: (row, col) pairs + device counter
+struct CkWorklist {
+    int2* items;
+    unsigned* count;
+    unsigned cap;
+};
+// which panels one assembly launch covers: Sigma -- the owned panels (tile0[j] = index of the first
+// 64-row tile of the j-th owned panel, panel_of[j] = its block column, sigptr[K] = its storage);
+// right-hand sides -- n_panels panels of aux_tiles tiles each, contiguous from `aux`
+struct CkPanelMap {
+    const int* tile0;
+    const int* panel_of;
+    double* const* sigptr;
+    int n_panels;
+    double* aux;
+    long aux_tiles;
+};
+// Sigma: every owned block column (rows K*NB.., ld = CK_NB) in ONE launch.
 // c: 3 x npad exact-formula coordinates, u: 3 x npad chord vectors.  fast: table path.
-void ck_launch_assemble_sigma_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                                    const double* const* coefs, int metric, const double* c, const double* u,
-                                    CkLayout L, int64_t row0, int64_t nrows, int64_t col0, double* out);
-// One block column of the right-hand-side rows: rows = prediction sites p in [0, m) (row m = data
-// values z, rows > m zero), cols = data sites [col0, col0 + CK_NB).
-void ck_launch_assemble_aux_panel(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                                  const double* const* coefs, int metric, int i_pred, const double* pc,
-                                  const double* pu, int64_t m, int64_t mpad, const double* c, const double* u,
-                                  const double* z, CkLayout L, int64_t col0, double* out);
+void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                              const double* const* coefs, int metric, const double* c, const double* u, CkLayout L,
+                              CkPanelMap pm, int total_tiles, CkWorklist wl);
+// right-hand-side rows, every block column in one launch: rows = prediction sites p in [0, m)
+// (row m = data values z, rows > m zero), cols = data sites.
+void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
+                            const double* const* coefs, int metric, int i_pred, const double* pc, const double* pu,
+                            int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
+                            int n_panels, double* aux, CkWorklist wl);
+// evaluate the deferred entries of the preceding table-path launches (no-op when the list is empty)
+void ck_launch_assemble_fix(hipStream_t s, bool aux_rows, const CkMatern* blk, int metric, int i_pred,
+                            const double* pc, int64_t mpad, const double* c, CkLayout L, CkWorklist wl,
+                            double* const* sigptr, double* aux);
 // dense a x b block for one (i, j) Matern block; mode 0 = covariance, 1 = distance only
 void ck_launch_cov_dense(hipStream_t s, const CkMatern* blk_ij, int metric, int add_nugget, int mode,
                          const double* a0, const double* a1, const double* a2, int64_t a, const double* b0,
