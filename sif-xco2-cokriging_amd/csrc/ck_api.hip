@@ -285,10 +285,10 @@ extern "C" int ck_set_data(ck_handle* h, int k, const double* coords, const doub
 static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------
-// tabulated correlation: build log rho(q) tables for every Matern block of the model
-// (ck_math.h "Tabulated correlation").  Node values come from the exact device evaluator;
-// the degree-10 Chebyshev fit per interval is done here in long double; the result is
-// checked on the device against the exact evaluator and disabled if it misses 2e-13.
+// tabulated covariance: build C(q) = amp * rho tables for every Matern block of the model
+// (ck_math.h "Tabulated covariance").  Node values come from the exact device evaluator;
+// the Chebyshev fit per interval is done here in long double; the result is checked on the
+// device against the exact evaluator (k_table_check) and disabled if it misses 2e-13.
 // ---------------------------------------------------------------------------------------
 static int build_tables(ck_handle* h, double qbox_euclid) {
     const int nblk = h->n_procs == 1 ? 1 : 3;
@@ -302,14 +302,14 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     if (!h->d_tabs) {
         HIPCHK(hipMalloc((void**)&h->d_tabs, 3 * sizeof(CkTable)));
         HIPCHK(hipMalloc((void**)&h->d_coefptr, 3 * sizeof(double*)));
-        for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void**)&h->d_coef[b], (size_t)ND * CK_TAB_MAXINT * 8));
+        for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void**)&h->d_coef[b], (size_t)ND * CK_TAB_STRIDE * 8));
     }
     unsigned long long* d_err = nullptr;
     double *d_q = nullptr, *d_f = nullptr;
     HIPCHK(hipMalloc((void**)&d_err, 8));
-    HIPCHK(hipMalloc((void**)&d_q, (size_t)ND * CK_TAB_MAXINT * 8));
-    HIPCHK(hipMalloc((void**)&d_f, (size_t)ND * CK_TAB_MAXINT * 8));
-    std::vector<double> hq(ND * CK_TAB_MAXINT), hf(ND * CK_TAB_MAXINT), hcoef(ND * CK_TAB_MAXINT);
+    HIPCHK(hipMalloc((void**)&d_q, (size_t)ND * CK_TAB_STRIDE * 8));
+    HIPCHK(hipMalloc((void**)&d_f, (size_t)ND * CK_TAB_STRIDE * 8));
+    std::vector<double> hq(ND * CK_TAB_STRIDE), hf(ND * CK_TAB_STRIDE), hcoef(ND * CK_TAB_STRIDE);
     for (int b = 0; b < 3; ++b) {
         CkTable& T = h->tab[b];
         memset(&T, 0, sizeof(T));
@@ -326,18 +326,12 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hf.data(), d_f, (size_t)n_int * ND * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        // drop the far tail where rho has underflowed (log rho = -inf): the exact path returns 0 there
-        int n_ok = n_int;
-        for (int it = 0; it < n_int && n_ok == n_int; ++it)
-            for (int j = 0; j < ND; ++j)
-                if (!(fabs(hf[it * ND + j]) < 1e300)) {
-                    n_ok = it;
-                    break;
-                }
-        n_int = n_ok;
-        if (n_int <= 0) continue;
-        ck_table_fit(hf.data(), n_int, hcoef.data());
-        HIPCHK(hipMemcpyAsync(h->d_coef[b], hcoef.data(), (size_t)ND * n_int * 8, hipMemcpyHostToDevice, h->stream));
+        // node values must be finite (they are: rho underflows to 0 far in the tail)
+        bool finite = true;
+        for (int64_t i = 0; i < (int64_t)n_int * ND; ++i) finite = finite && (fabs(hf[i]) < 1e300);
+        if (!finite) continue;
+        ck_table_fit(hf.data(), n_int, base, hcoef.data());
+        HIPCHK(hipMemcpyAsync(h->d_coef[b], hcoef.data(), (size_t)ND * CK_TAB_STRIDE * 8, hipMemcpyHostToDevice, h->stream));
         T.base = (int32_t)base;
         T.n_int = n_int;
         T.q_lo = ck_table_edge(base);

@@ -63,9 +63,8 @@ __device__ __forceinline__ double pair_dist(int metric, double a0, double a1, do
 // identity (Sigma) or are zero (right-hand sides), so the factorisation of the padded matrix is
 // the factorisation of the real one.
 //
-// grid (CK_NB / 256, rows / 64), 256 threads; a workgroup walks four 64 x 64 sub-tiles.
-// thread (ty = t >> 4, tx = t & 15) computes rows ty + 16 a (a = 0..3), cols 2 tx + {0, 1} + 32 b
-// (b = 0, 1): every store instruction of a wave writes 4 rows x 256 contiguous bytes.
+// One launch covers all panels: a workgroup (256 threads) owns one 64-row x 512-column strip of
+// a panel and walks its eight 64 x 64 sub-tiles (assemble_subtile).
 struct CkSiteRef {   // SoA views of one site set
     const double *c0, *c1, *c2;   // exact-formula coordinates (lat_rad, lon_rad, cos lat | x, y, 0)
     const double *u0, *u1, *u2;   // chord vectors (table path)
@@ -80,45 +79,6 @@ __device__ __forceinline__ bool site_valid(const CkLayout& L, long g) {
 __device__ __noinline__ double exact_entry_call(const CkMatern* m, int metric, int nug, double ac0, double ac1,
                                                 double ac2, double bc0, double bc1, double bc2) {
     return ck_cov_entry(*m, pair_dist(metric, ac0, ac1, ac2, bc0, bc1, bc2), nug);
-}
-
-// exp(p) for p <= 0 (log rho is never positive): no overflow handling, underflow through ldexp
-__device__ __forceinline__ double ck_exp_nonpos(double p) {
-    const double n = rint(p * 1.4426950408889634074);                 // p / ln 2
-    double r = fma(n, -6.93147180369123816490e-01, p);               // ln 2 hi
-    r = fma(n, -1.90821492927058770002e-10, r);                      // ln 2 lo
-    double e = 2.50521083854417187751e-08;                           // 1/11!
-    e = fma(e, r, 2.75573192239858906526e-07);
-    e = fma(e, r, 2.75573192239858906526e-06);
-    e = fma(e, r, 2.48015873015873015873e-05);
-    e = fma(e, r, 1.98412698412698412698e-04);
-    e = fma(e, r, 1.38888888888888888889e-03);
-    e = fma(e, r, 8.33333333333333333333e-03);
-    e = fma(e, r, 4.16666666666666666667e-02);
-    e = fma(e, r, 1.66666666666666666667e-01);
-    e = fma(e, r, 0.5);
-    e = fma(e, r, 1.0);
-    e = fma(e, r, 1.0);
-    return ldexp(e, (int)n);
-}
-
-// One entry through the table.  Pairs outside the table's range (closer than its lower end, or
-// beyond its upper end) are NOT evaluated here: the caller collects them in a per-thread bit mask
-// and appends their (row, col) to a worklist that k_assemble_fix evaluates with the exact formulas
-// afterwards.  Keeping the Bessel code out of this kernel halves its register count.
-__device__ __forceinline__ double fast_entry(const CkMatern& m, const CkTable& tab, const double* lcoef, double ac0,
-                                             double ac1, double au0, double au1, double au2, double bc0, double bc1,
-                                             double bu0, double bu1, double bu2, int nug, bool valid, bool* slow) {
-    const bool same = (ac0 == bc0 && ac1 == bc1);   // h == 0 exactly (model.py:195-196)
-    const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
-    const double q = dx * dx + dy * dy + dz * dz;
-    const bool in_tab = (q >= tab.q_lo && q < tab.q_hi);
-    int iv;
-    const double x = ck_table_x(in_tab ? q : tab.q_lo, &iv, tab.base);   // keep the lookup in range
-    double val = m.amp * ck_exp_nonpos(ck_table_logrho(lcoef, tab.n_int, iv, x));
-    if (same) val = nug ? m.amp + m.nugget : m.amp;
-    *slow = valid && !same && !in_tab;              // padding lanes never ask for the exact formulas
-    return val;
 }
 
 // append this thread's deferred entries (bit k of `mask` = entry k of the sub-tile) to the worklist
@@ -141,6 +101,95 @@ __device__ __noinline__ void worklist_append(const CkWorklist& wl, unsigned mask
     }
 }
 
+// this thread's four rows of a 64-row tile
+struct CkRowRegs {
+    double c0[4], c1[4], c2[4];   // exact path
+    double u0[4], u1[4], u2[4];   // table path
+    bool v[4];
+};
+
+// One 64 x 64 sub-tile.  thread (ty, tx) computes rows ty + 16 a (a = 0..3), cols 2 tx + {0, 1} +
+// 32 b (b = 0, 1): every store instruction of a wave writes 4 rows x 256 contiguous bytes.
+//
+// FAST: one entry = squared chord, interval index + centre from its bit pattern, 8 LDS reads,
+// 7 FMA.  Pairs outside the table's range (closer than its lower end -- which includes h == 0
+// and with it the nugget -- or beyond its upper end) are NOT evaluated here: their bit goes into
+// the returned mask and the caller appends (row, col) to a worklist that k_assemble_fix evaluates
+// with the exact formulas afterwards; what this kernel stores for them is overwritten.  Keeping
+// the Bessel code out of this kernel halves its register count.
+// PAD: the tile touches padding rows or columns (identity / z row / zeros); the interior tiles
+// skip all of that.
+template <bool FAST, bool AUX, bool PAD>
+__device__ __forceinline__ unsigned assemble_subtile(const CkMatern& mb, int metric, const double* lcoef, int tbase,
+                                                     unsigned tn, const CkRowRegs& R, const CkSiteRef& S,
+                                                     const double* __restrict__ z, const CkLayout& L, long rt,
+                                                     long ct, long m, int nug, double* __restrict__ obase, int ty,
+                                                     int tx) {
+    unsigned slowmask = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const long c = ct + 2 * tx + 32 * b;
+        double cc0[2], cc1[2], cc2[2], cu0[2], cu1[2], cu2[2];
+        bool cv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            cv[e] = PAD ? site_valid(L, c + e) : true;
+            if (FAST) {
+                cu0[e] = S.u0[c + e];
+                cu1[e] = S.u1[c + e];
+                cu2[e] = S.u2[c + e];
+            } else {
+                cc0[e] = S.c0[c + e];
+                cc1[e] = S.c1[c + e];
+                cc2[e] = S.c2[c + e];
+            }
+        }
+        double zc[2] = {0.0, 0.0};
+        if (AUX && PAD) {
+            zc[0] = z[c];
+            zc[1] = z[c + 1];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long r = rt + ty + 16 * a;
+            d2_t v;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                double val = 0.0;
+                const bool valid = PAD ? (R.v[a] && cv[e]) : true;
+                if (FAST) {
+                    const double dx = R.u0[a] - cu0[e], dy = R.u1[a] - cu1[e], dz = R.u2[a] - cu2[e];
+                    const double q = dx * dx + dy * dy + dz * dz;
+                    int iv;
+                    const double y = ck_table_y(q, &iv, tbase);
+                    const bool slow = valid && (unsigned)iv >= tn;   // q == 0 lands here too
+                    iv = min(max(iv, 0), (int)tn - 1);               // keep the lookup inside the table
+                    val = ck_table_poly(lcoef, iv, y);
+                    slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
+                } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
+                    if (valid) val = exact_entry_call(&mb, metric, nug, R.c0[a], R.c1[a], R.c2[a], cc0[e], cc1[e], cc2[e]);
+                }
+                if (PAD) {
+                    if (AUX) {
+                        // rows: prediction sites | z | zero padding; padded columns are zero
+                        if (!R.v[a]) val = (r == m) ? zc[e] : 0.0;
+                        if (!cv[e]) val = 0.0;
+                    } else {
+                        if (!valid) val = (r == c + e) ? 1.0 : 0.0;   // padding: identity
+                    }
+                }
+                v[e] = val;
+            }
+            *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
+        }
+    }
+    return slowmask;
+}
+
+__device__ __forceinline__ bool range_has_padding(const CkLayout& L, long g0) {   // [g0, g0 + 64)
+    return !(g0 + 64 <= L.n0 || (g0 >= L.n0p && g0 + 64 <= L.nend));
+}
+
 // FAST: table path (every block's table enabled) | exact per-entry Bessel evaluation.
 // AUX:  rows are prediction sites (row m = data values z, rows > m zero) | rows are data sites.
 template <bool FAST, bool AUX>
@@ -150,8 +199,7 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
                                                                  int i_pred, CkSiteRef R, long m, CkSiteRef S,
                                                                  const double* __restrict__ z, CkLayout L,
                                                                  CkPanelMap pm, CkWorklist wl) {
-    __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_MAXINT : 1];
-    __shared__ CkTable ltab;
+    __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_STRIDE : 1];
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
     // blockIdx.x enumerates the 64-row tiles of ALL panels of this launch; a workgroup walks the
     // eight 64 x 64 sub-tiles of its 64 x 512 strip
@@ -174,25 +222,25 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
     }
     const long rt = row0 + tile * 64;
     const int pr = AUX ? i_pred : (int)(rt >= L.n0p);
-    // this thread's four rows
-    double rc0[4], rc1[4], rc2[4], ru0[4], ru1[4], ru2[4];
-    bool rv[4];
+    const bool row_pad = AUX ? (rt + 64 > m) : range_has_padding(L, rt);
+    CkRowRegs rr;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const long r = rt + ty + 16 * a;
-        rv[a] = AUX ? (r < m) : site_valid(L, r);
-        rc0[a] = R.c0[r];
-        rc1[a] = R.c1[r];
-        rc2[a] = FAST ? 0.0 : R.c2[r];
+        rr.v[a] = AUX ? (r < m) : site_valid(L, r);
         if (FAST) {
-            ru0[a] = R.u0[r];
-            ru1[a] = R.u1[r];
-            ru2[a] = R.u2[r];
+            rr.u0[a] = R.u0[r];
+            rr.u1[a] = R.u1[r];
+            rr.u2[a] = R.u2[r];
+        } else {
+            rr.c0[a] = R.c0[r];
+            rr.c1[a] = R.c1[r];
+            rr.c2[a] = R.c2[r];
         }
     }
-    int loaded = -1;
-    for (int sub = 0; sub < CK_NB / 64; ++sub) {   // the whole panel width: one table load per 256 KB of output
-        unsigned slowmask = 0;
+    int loaded = -1, tbase = 0;
+    unsigned tn = 1;
+    for (int sub = 0; sub < CK_NB / 64; ++sub) {
         const long ct = col0 + sub * 64;
         const int pc = (int)(ct >= L.n0p);
         const int bidx = pr + pc;
@@ -201,66 +249,24 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
         double* obase = out + (rt - row0) * CK_NB + (ct - col0);
         if (FAST && loaded != bidx) {
             __syncthreads();
-            if (t == 0) ltab = tabs[bidx];
-            const int cnt = (CK_TAB_DEG + 1) * tabs[bidx].n_int;
             const double* src = coefs[bidx];
-            for (int k = t; k < cnt; k += 256) lcoef[k] = src[k];
+            for (int k = t; k < (CK_TAB_DEG + 1) * CK_TAB_STRIDE; k += 256) lcoef[k] = src[k];
+            tbase = tabs[bidx].base;
+            tn = (unsigned)tabs[bidx].n_int;
             __syncthreads();
             loaded = bidx;
         }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const long c = ct + 2 * tx + 32 * b;
-            double cc0[2], cc1[2], cc2[2], cu0[2], cu1[2], cu2[2];
-            bool cv[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                cv[e] = site_valid(L, c + e);
-                cc0[e] = S.c0[c + e];
-                cc1[e] = S.c1[c + e];
-                cc2[e] = FAST ? 0.0 : S.c2[c + e];
-                if (FAST) {
-                    cu0[e] = S.u0[c + e];
-                    cu1[e] = S.u1[c + e];
-                    cu2[e] = S.u2[c + e];
-                }
-            }
-            const double zc[2] = {AUX ? z[c] : 0.0, AUX ? z[c + 1] : 0.0};
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const long r = rt + ty + 16 * a;
-                d2_t v;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    double val = 0.0;
-                    const bool valid = rv[a] && cv[e];
-                    if (FAST) {
-                        bool slow;
-                        val = fast_entry(mb, ltab, lcoef, rc0[a], rc1[a], ru0[a], ru1[a], ru2[a], cc0[e], cc1[e],
-                                         cu0[e], cu1[e], cu2[e], nug, valid, &slow);
-                        slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
-                    } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
-                        if (valid)
-                            val = exact_entry_call(&mb, metric, nug, rc0[a], rc1[a], rc2[a], cc0[e], cc1[e], cc2[e]);
-                    }
-                    if (AUX) {
-                        // rows: prediction sites | z | zero padding; padded columns are zero
-                        if (!rv[a]) val = (r == m) ? zc[e] : 0.0;
-                        if (!cv[e]) val = 0.0;
-                    } else {
-                        if (!(rv[a] && cv[e])) val = (r == c + e) ? 1.0 : 0.0;   // padding: identity
-                    }
-                    v[e] = val;
-                }
-                *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-            }
-        }
+        unsigned slowmask;
+        if (!FAST || row_pad || range_has_padding(L, ct))
+            slowmask = assemble_subtile<FAST, AUX, true>(mb, metric, lcoef, tbase, tn, rr, S, z, L, rt, ct, m, nug, obase, ty, tx);
+        else
+            slowmask = assemble_subtile<FAST, AUX, false>(mb, metric, lcoef, tbase, tn, rr, S, z, L, rt, ct, m, nug, obase, ty, tx);
         if (FAST && __builtin_amdgcn_ballot_w64(slowmask != 0u) != 0ULL)   // rare: hand the pairs to the exact pass
             worklist_append(wl, slowmask, (int)(rt + ty), 16, (int)(ct + 2 * tx));
     }
 }
 
-// Exact evaluation of the worklist entries (see fast_entry).  Sigma: entry (r, c) lives in panel
+// Exact evaluation of the worklist entries (see assemble_subtile).  Sigma: entry (r, c) lives in panel
 // K = c / NB at sigptr[K] + (r - K NB) NB + (c - K NB); right-hand sides: aux + K mpad NB + r NB + ...
 template <bool AUX>
 __global__ __launch_bounds__(256) void k_assemble_fix(const CkMatern* __restrict__ blk, int metric, int i_pred,
@@ -367,12 +373,12 @@ void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, c
 // =========================================================================================
 // Tabulated fast path (ck_math.h "Tabulated correlation")
 // =========================================================================================
-// log rho at given squared chords q (table construction; the polynomial fit is done on the host)
+// C = amp * rho at given squared chords q (table construction; the polynomial fit is done on the host)
 __global__ void k_table_nodes(const CkMatern* __restrict__ m, int metric, const double* __restrict__ q, long n,
                               double* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = log(ck_matern_rho_scaled(*m, ck_s_of_q(*m, metric, q[i])));
+    out[i] = m->amp * ck_matern_rho_scaled(*m, ck_s_of_q(*m, metric, q[i]));
 }
 
 void ck_launch_table_nodes(hipStream_t s, const CkMatern* m, int metric, const double* q, int64_t n, double* out) {
@@ -380,7 +386,10 @@ void ck_launch_table_nodes(hipStream_t s, const CkMatern* m, int metric, const d
     k_table_nodes<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(m, metric, q, n, out);
 }
 
-// max relative error of exp(P) against the exact evaluator, 8 probe points per interval
+// Table error against the exact evaluator, 8 probe points per interval:
+//   |table - amp rho| / (|amp| max(rho, 1e-6))
+// i.e. the relative error of the entry while rho >= 1e-6 and the absolute error in units of
+// 1e-6 amp below that (ck_math.h explains why the tail is judged absolutely).
 __global__ void k_table_check(const CkMatern* __restrict__ m, int metric, CkTable tab,
                               const double* __restrict__ coef, unsigned long long* __restrict__ max_err_bits) {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,13 +400,14 @@ __global__ void k_table_check(const CkMatern* __restrict__ m, int metric, CkTabl
     b.u = (unsigned long long)(tab.base + interval + 1) << CK_TAB_SHIFT;
     const double q = a.d + (0.03125 + 0.125 * j) * (b.d - a.d);
     int iv;
-    const double x = ck_table_x(q, &iv, tab.base);
-    const double got = exp(ck_table_logrho(coef, tab.n_int, iv, x));
-    const double ref = ck_matern_rho_scaled(*m, ck_s_of_q(*m, metric, q));
-    double e = 0.0;
-    if (ref > 1e-290) e = fabs(got / ref - 1.0);
-    else e = fabs(got - ref) > 1e-290 ? 1.0 : 0.0;
-    if (iv != interval) e = 1.0;
+    const double y = ck_table_y(q, &iv, tab.base);
+    double e = 1.0;
+    if (iv == interval) {
+        const double got = ck_table_poly(coef, iv, y);
+        const double rho = ck_matern_rho_scaled(*m, ck_s_of_q(*m, metric, q));
+        e = m->amp == 0.0 ? fabs(got) : fabs(got - m->amp * rho) / (fabs(m->amp) * fmax(rho, 1e-6));
+        if (!(e < 1.0)) e = 1.0;
+    }
     union { double d; unsigned long long u; } ev;
     ev.d = e;
     atomicMax(max_err_bits, ev.u);   // non-negative doubles order like their bit patterns

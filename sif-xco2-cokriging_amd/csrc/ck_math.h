@@ -215,20 +215,28 @@ CK_HD double ck_matern_rho_scaled(const CkMatern& m, double s) {
 }
 
 // --------------------------------------------------------------------------
-// Tabulated correlation (fast assembly path)
+// Tabulated covariance (fast assembly path)
 // --------------------------------------------------------------------------
-// For one Matern block, log rho is tabulated as a function of q, the SQUARED chord
+// For one Matern block, C(q) = amp * rho is tabulated as a function of q, the SQUARED chord
 // (haversine: q = |u_i - u_j|^2 on the unit sphere, d = 2 R asin(sqrt(q)/2); Euclid: q = d^2).
-// q-space is cut at the double's exponent and top 3 mantissa bits (8 sub-intervals per octave),
-// so the interval index is one shift of the bit pattern; on every interval log rho is a
-// degree-10 polynomial in x in [-1, 1).  The nearest singularity of log rho(q) is q = 0, 23
-// half-widths away, so the Chebyshev interpolant converges like 46^-k: degree 10 is at the
-// rounding floor.  rho = exp(P(x)) costs 10 FMA + one exp instead of a Bessel evaluation plus
-// sqrt/asin/sin.  Coefficients are k-major (coef[k * n_int + interval]) so that lanes on
-// neighbouring intervals read neighbouring LDS banks.
-#define CK_TAB_DEG 10
-#define CK_TAB_SHIFT 49            /* bits >> 49 = exponent and top 3 mantissa bits */
-#define CK_TAB_MAXINT 320
+// q-space is cut at the double's exponent and top 5 mantissa bits (32 sub-intervals per octave),
+// so the interval index is one shift of the bit pattern and the interval CENTRE is one
+// and-or of it; on every interval C is a degree-7 polynomial in y = q - centre (exact in
+// floating point).  The nearest singularity of rho(q) is q = 0, 65 half-widths away, so the
+// Chebyshev interpolant converges like 130^-k: degree 7 is at the rounding floor of the
+// leading term.  One entry costs an and-or, a subtract, 8 LDS reads and 7 FMA -- no exp, no
+// Bessel function, no sqrt/asin/sin.  Accuracy is ABSOLUTE in units of amp (what the
+// factorisation of Sigma responds to): far in the tail, where rho < 1e-6, the relative error
+// of rho itself grows (1e-12 at rho = 1e-14) while the absolute one keeps shrinking.
+// Coefficients are k-major with a fixed stride (coef[k * CK_TAB_STRIDE + interval]): lanes on
+// neighbouring intervals read neighbouring LDS banks and k becomes an immediate offset.
+#define CK_TAB_DEG 7
+#define CK_TAB_SHIFT 47            /* bits >> 47 = exponent and top 5 mantissa bits */
+#define CK_TAB_MAXINT 768          /* 24 octaves; 8 x 769 doubles = 48 KB of LDS */
+// k-stride in doubles.  NOT a multiple of 64: with a 512-byte-multiple stride hipcc fuses the
+// reads of two coefficients into ds_read2st64_b64, which runs at half the rate of two
+// ds_read_b64 and banks modulo 32 instead of 64 (MI355X_MICROARCH.md, LDS table).
+#define CK_TAB_STRIDE 769
 
 struct CkTable {
     double q_lo, q_hi;     // table covers q_lo <= q < q_hi (interval aligned); outside: exact evaluator
@@ -236,23 +244,26 @@ struct CkTable {
     int32_t n_int;         // number of intervals
     int32_t enabled;       // 0: use the exact evaluator for this block
     int32_t pad_;
-    double max_rel_err;    // measured against the exact evaluator when the table was built
+    double max_rel_err;    // measured against the exact evaluator when the table was built (see k_table_check)
 };
 
-CK_HD double ck_table_x(double q, int* interval, int base) {
-    union { double d; uint64_t u; } v;
+// interval index of q relative to `base` (may lie outside [0, n_int): the caller decides) and
+// y = q - centre of q's interval
+CK_HD double ck_table_y(double q, int* interval, int base) {
+    union { double d; uint64_t u; } v, c;
     v.d = q;
-    *interval = (int)(v.u >> CK_TAB_SHIFT) - base;
-    v.u = ((v.u & ((1ULL << CK_TAB_SHIFT) - 1)) << 3) | 0x3FF0000000000000ULL;   // [1, 2)
-    return 2.0 * (v.d - 1.0) - 1.0;
+    const uint32_t hi = (uint32_t)(v.u >> 32);
+    *interval = (int)(hi >> (CK_TAB_SHIFT - 32)) - base;
+    c.u = (uint64_t)((hi & ~((1u << (CK_TAB_SHIFT - 32)) - 1u)) | (1u << (CK_TAB_SHIFT - 33))) << 32;
+    return q - c.d;
 }
 
-CK_HD double ck_table_logrho(const double* coef, int n_int, int interval, double x) {
-    double p = coef[CK_TAB_DEG * n_int + interval];
+CK_HD double ck_table_poly(const double* coef, int interval, double y) {
+    double p = coef[CK_TAB_DEG * CK_TAB_STRIDE + interval];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int k = CK_TAB_DEG - 1; k >= 0; --k) p = p * x + coef[k * n_int + interval];
+    for (int k = CK_TAB_DEG - 1; k >= 0; --k) p = p * y + coef[k * CK_TAB_STRIDE + interval];
     return p;
 }
 

@@ -134,7 +134,7 @@ static long double cheb_node(int j) {
     return cosl(PI * (j + 0.5L) / CK_ND);
 }
 
-// Decide the q-range of the table for one block and emit the Chebyshev nodes (n_int x 11 values
+// Decide the q-range of the table for one block and emit the Chebyshev nodes (n_int x CK_ND values
 // of q, interval-major).  Lower end: scaled lag 1/64 (closer pairs take the exact formulas);
 // upper end: q = 2 on the sphere (10 007 km) or 4x the squared bounding-box diagonal of the data.
 extern "C" int ck_table_plan(const CkMatern* m, int metric, double qbox_euclid, int64_t* base_out, double* q_nodes) {
@@ -168,8 +168,12 @@ extern "C" int ck_table_plan(const CkMatern* m, int metric, double qbox_euclid, 
     return n_int;
 }
 
-// node values f (n_int x 11, interval-major) -> monomial coefficients in x in [-1, 1), k-major
-extern "C" void ck_table_fit(const double* f, int n_int, double* coef_kmajor) {
+// node values f (n_int x CK_ND, interval-major) -> coefficients of the polynomial in
+// y = q - centre, k-major with stride CK_TAB_STRIDE (coef[k * CK_TAB_STRIDE + interval]; the
+// caller provides CK_ND * CK_TAB_STRIDE doubles).  The fit is a Chebyshev interpolant in the
+// normalised x = 2 y / width, converted to monomials and rescaled by (2 / width)^k -- widths are
+// powers of two, so the rescaling is exact.
+extern "C" void ck_table_fit(const double* f, int n_int, int64_t base, double* coef_kmajor) {
     const long double PI = 3.14159265358979323846264338327950288L;
     long double Tm[CK_ND][CK_ND];   // Tm[k][i]: coefficient of x^i in the Chebyshev polynomial T_k
     for (int k = 0; k < CK_ND; ++k)
@@ -178,6 +182,7 @@ extern "C" void ck_table_fit(const double* f, int n_int, double* coef_kmajor) {
     Tm[1][1] = 1;
     for (int k = 2; k < CK_ND; ++k)
         for (int i = 0; i < CK_ND; ++i) Tm[k][i] = (i > 0 ? 2 * Tm[k - 1][i - 1] : 0) - Tm[k - 2][i];
+    for (size_t i = 0; i < (size_t)CK_ND * CK_TAB_STRIDE; ++i) coef_kmajor[i] = 0.0;
     for (int it = 0; it < n_int; ++it) {
         long double ck[CK_ND];
         for (int k = 0; k < CK_ND; ++k) {
@@ -185,10 +190,13 @@ extern "C" void ck_table_fit(const double* f, int n_int, double* coef_kmajor) {
             for (int j = 0; j < CK_ND; ++j) acc += (long double)f[it * CK_ND + j] * cosl(PI * k * (j + 0.5L) / CK_ND);
             ck[k] = acc * (k == 0 ? 1.0L : 2.0L) / CK_ND;
         }
+        const long double scale = 2.0L / ((long double)ck_table_edge(base + it + 1) - (long double)ck_table_edge(base + it));
+        long double pw = 1.0L;
         for (int i = 0; i < CK_ND; ++i) {
             long double a = 0;
             for (int k = 0; k < CK_ND; ++k) a += ck[k] * Tm[k][i];
-            coef_kmajor[(size_t)i * n_int + it] = (double)a;
+            coef_kmajor[(size_t)i * CK_TAB_STRIDE + it] = (double)(a * pw);
+            pw *= scale;
         }
     }
 }

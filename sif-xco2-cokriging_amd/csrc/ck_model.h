@@ -11,7 +11,7 @@ void ck_model_prepare(int n_procs, const double* sigma, const double* nu, const 
 // tabulated correlation (ck_math.h): interval plan, Chebyshev fit
 double ck_table_edge(int64_t interval_index);
 int ck_table_plan(const CkMatern* m, int metric, double qbox_euclid, int64_t* base_out, double* q_nodes);
-void ck_table_fit(const double* node_values, int n_int, double* coef_kmajor);
+void ck_table_fit(const double* node_values, int n_int, int64_t base, double* coef_kmajor);
 #ifdef __cplusplus
 }
 #endif

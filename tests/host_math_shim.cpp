@@ -58,32 +58,27 @@ extern "C" double shim_table_max_err(double nu, double len_scale, int metric, do
                                      double* q_lo_out, double* q_hi_out) {
     CkMatern m;
     ck_matern_prepare(nu, len_scale, 1.0, 0.0, &m);
-    static double q[(CK_TAB_DEG + 1) * CK_TAB_MAXINT], f[(CK_TAB_DEG + 1) * CK_TAB_MAXINT],
-        coef[(CK_TAB_DEG + 1) * CK_TAB_MAXINT];
+    static double q[(CK_TAB_DEG + 1) * CK_TAB_STRIDE], f[(CK_TAB_DEG + 1) * CK_TAB_STRIDE],
+        coef[(CK_TAB_DEG + 1) * CK_TAB_STRIDE];
     int64_t base = 0;
     int n_int = ck_table_plan(&m, metric, qbox, &base, q);
     const int ND = CK_TAB_DEG + 1;
-    int n_ok = n_int;
-    for (int k = 0; k < n_int * ND; ++k) {
-        f[k] = log(ck_matern_rho_scaled(m, ck_s_of_q(m, metric, q[k])));
-        if (!(fabs(f[k]) < 1e300) && k / ND < n_ok) n_ok = k / ND;
-    }
-    n_int = n_ok;
-    ck_table_fit(f, n_int, coef);
+    for (int k = 0; k < n_int * ND; ++k) f[k] = m.amp * ck_matern_rho_scaled(m, ck_s_of_q(m, metric, q[k]));
+    ck_table_fit(f, n_int, base, coef);
     *n_int_out = n_int;
     *q_lo_out = ck_table_edge(base);
     *q_hi_out = ck_table_edge(base + n_int);
-    double worst = 0;
+    double worst = 0;   // same measure as k_table_check: |err| / (amp max(rho, 1e-6))
     for (int it = 0; it < n_int; ++it)
         for (int j = 0; j < 16; ++j) {
             const double qa = ck_table_edge(base + it), qb = ck_table_edge(base + it + 1);
             const double qq = qa + (0.015625 + 0.0625 * j) * (qb - qa);
             int iv;
-            const double x = ck_table_x(qq, &iv, (int)base);
+            const double y = ck_table_y(qq, &iv, (int)base);
             if (iv != it) return 1e9;
-            const double got = exp(ck_table_logrho(coef, n_int, iv, x));
+            const double got = ck_table_poly(coef, iv, y);
             const double ref = ck_matern_rho_scaled(m, ck_s_of_q(m, metric, qq));
-            if (ref > 1e-290) worst = fmax(worst, fabs(got / ref - 1.0));
+            worst = fmax(worst, fabs(got - ref) / fmax(ref, 1e-6));
         }
     return worst;
 }

@@ -159,8 +159,13 @@ def test_assemble_and_factor_vs_oracle(native, exact, tag):
     N = 400
     S = orc.joint_cov(p, coords, HAV)
     low = h.debug_get_lower(N)
-    # 5e-13 relative; entries below 1e-30 (e^-70 of the variance) only to 1e-30 absolute
-    np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=1e-30)
+    if exact:
+        # 5e-13 relative; entries below 1e-30 (e^-70 of the variance) only to 1e-30 absolute
+        np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=1e-30)
+    else:
+        # the table is gated on |err| <= 2e-13 |amp| max(rho, 1e-6) (k_table_check): relative down to
+        # rho = 1e-6, absolute in units of 1e-6 of the variance below
+        np.testing.assert_allclose(low, np.tril(S), rtol=5e-13, atol=5e-19 * np.max(np.diag(S)))
     assert h.factor() == 0
     L = h.debug_get_lower(N)
     Lref = np.linalg.cholesky(S)

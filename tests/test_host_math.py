@@ -87,3 +87,20 @@ def test_haversine_vs_oracle(shim):
     shim.shim_haversine(A.ctypes.data_as(dp), ctypes.c_long(len(A)), A.ctypes.data_as(dp), ctypes.c_long(len(A)),
                         out2.ctypes.data_as(dp))
     assert np.array_equal(out2 == 0, g["hav_AA"] == 0)
+
+
+@pytest.mark.parametrize("nu,len_scale,metric,qbox", [
+    (0.5, 300.0, 0, 0.0), (1.5, 800.0, 0, 0.0), (2.5, 150.0, 0, 0.0), (0.8, 500.0, 0, 0.0), (3.3, 1200.0, 0, 0.0),
+    (0.5, 0.2, 1, 2.0), (1.5, 0.3, 1, 2.0), (0.75, 0.1, 1, 2.0), (2.25, 0.5, 1, 2.0),
+])
+def test_covariance_table_error(shim, nu, len_scale, metric, qbox):
+    """Tabulated covariance (ck_math.h "Tabulated covariance"; plan + fit in csrc/ck_model.cpp) against the
+    exact evaluator, 16 probes per interval, in the measure k_table_check gates on:
+    |table - rho| / max(rho, 1e-6) for amp = 1.  metric 0 = haversine, 1 = Euclid (qbox = squared extent)."""
+    n_int, q_lo, q_hi = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+    shim.shim_table_max_err.restype = ctypes.c_double
+    err = shim.shim_table_max_err(ctypes.c_double(nu), ctypes.c_double(len_scale), ctypes.c_int(metric),
+                                  ctypes.c_double(qbox), ctypes.byref(n_int), ctypes.byref(q_lo), ctypes.byref(q_hi))
+    assert 0 < n_int.value <= 768
+    assert 0.0 < q_lo.value < q_hi.value
+    assert err < 5e-14, (nu, err)
