@@ -101,87 +101,118 @@ __device__ __noinline__ void worklist_append(const CkWorklist& wl, unsigned mask
     }
 }
 
-// this thread's four rows of a 64-row tile
-struct CkRowRegs {
-    double c0[4], c1[4], c2[4];   // exact path
-    double u0[4], u1[4], u2[4];   // table path
-    bool v[4];
-};
-
 // One 64 x 64 sub-tile.  thread (ty, tx) computes rows ty + 16 a (a = 0..3), cols 2 tx + {0, 1} +
 // 32 b (b = 0, 1): every store instruction of a wave writes 4 rows x 256 contiguous bytes.
 //
-// FAST: one entry = squared chord, interval index + centre from its bit pattern, 8 LDS reads,
-// 7 FMA.  Pairs outside the table's range (closer than its lower end -- which includes h == 0
-// and with it the nugget -- or beyond its upper end) are NOT evaluated here: their bit goes into
-// the returned mask and the caller appends (row, col) to a worklist that k_assemble_fix evaluates
-// with the exact formulas afterwards; what this kernel stores for them is overwritten.  Keeping
-// the Bessel code out of this kernel halves its register count.
-// PAD: the tile touches padding rows or columns (identity / z row / zeros); the interior tiles
-// skip all of that.
-template <bool FAST, bool AUX, bool PAD>
-__device__ __forceinline__ unsigned assemble_subtile(const CkMatern& mb, int metric, const double* lcoef, int tbase,
-                                                     unsigned tn, const CkRowRegs& R, const CkSiteRef& S,
-                                                     const double* __restrict__ z, const CkLayout& L, long rt,
-                                                     long ct, long m, int nug, double* __restrict__ obase, int ty,
-                                                     int tx) {
+// Table path: one entry = squared chord, interval index + centre from its bit pattern, 8 LDS
+// reads, 7 FMA.  Pairs outside the table's range (closer than its lower end -- which includes
+// h == 0 and with it the nugget -- or beyond its upper end) are NOT evaluated here: their bit goes
+// into the returned mask and the caller appends (row, col) to a worklist that k_assemble_fix
+// evaluates with the exact formulas afterwards; what this kernel stores for them is overwritten.
+// Keeping the Bessel code out of this kernel halves its register count.
+//
+// Interior sub-tiles (no padding row or column; all but a few per panel), table path only.
+// ru*: the chord vectors of this thread's four rows.
+__device__ __forceinline__ unsigned assemble_subtile_interior(const double* lcoef, int tbase, unsigned tn,
+                                                              const double (&ru0)[4], const double (&ru1)[4],
+                                                              const double (&ru2)[4], const CkSiteRef& S, long ct,
+                                                              double* __restrict__ obase, int ty, int tx) {
     unsigned slowmask = 0;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const long c = ct + 2 * tx + 32 * b;
-        double cc0[2], cc1[2], cc2[2], cu0[2], cu1[2], cu2[2];
-        bool cv[2];
+        const d2_t cu0 = *reinterpret_cast<const d2_t*>(S.u0 + c), cu1 = *reinterpret_cast<const d2_t*>(S.u1 + c),
+                   cu2 = *reinterpret_cast<const d2_t*>(S.u2 + c);
+        // Two rows x two columns at a time: first the four squared chords, interval indices and
+        // offsets from the interval centres; then all 32 coefficient reads (k-major, so they return
+        // in the order Horner consumes them); then the four Horner chains interleaved.  The
+        // scheduling barriers keep hipcc from sinking each read next to its FMA, which would expose
+        // one LDS latency per Horner step.
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap) {
+            double y[4], cf[CK_TAB_DEG + 1][4];
+            const double* lp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int a = 2 * ap + (j >> 1), e = j & 1;
+                const double dx = ru0[a] - cu0[e], dy = ru1[a] - cu1[e], dz = ru2[a] - cu2[e];
+                const double q = dx * dx + dy * dy + dz * dz;
+                int iv;
+                y[j] = ck_table_y(q, &iv, tbase);
+                const bool slow = (unsigned)iv >= tn;            // q == 0 (and with it the nugget) lands here
+                slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
+                lp[j] = lcoef + min(max(iv, 0), (int)tn - 1);    // keep the lookup inside the table
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = CK_TAB_DEG; k >= 0; --k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cf[k][j] = lp[j][k * CK_TAB_STRIDE];
+            __builtin_amdgcn_sched_barrier(0);
+            double p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = cf[CK_TAB_DEG][j];
+#pragma unroll
+            for (int k = CK_TAB_DEG - 1; k >= 0; --k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = fma(p[j], y[j], cf[k][j]);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                d2_t v;
+                v[0] = p[2 * h2];
+                v[1] = p[2 * h2 + 1];
+                *reinterpret_cast<d2_t*>(obase + (ty + 16 * (2 * ap + h2)) * CK_NB + 2 * tx + 32 * b) = v;
+            }
+        }
+    }
+    return slowmask;
+}
+
+// Sub-tiles that touch padding rows or columns (identity / z row / zeros), and every sub-tile of
+// the exact path: entry by entry, loops kept rolled so that this rarely-run code stays small in
+// registers.  AUX: rows are prediction sites (row m = data values z, rows > m zero).
+template <bool FAST, bool AUX>
+__device__ __forceinline__ unsigned assemble_subtile_edge(const CkMatern& mb, int metric, const double* lcoef,
+                                                          int tbase, unsigned tn, const CkSiteRef& R,
+                                                          const CkSiteRef& S, const double* __restrict__ z,
+                                                          const CkLayout& L, long rt, long ct, long m, int nug,
+                                                          double* __restrict__ obase, int ty, int tx) {
+    unsigned slowmask = 0;
+#pragma unroll 1
+    for (int ba = 0; ba < 8; ++ba) {
+        const int b = ba >> 2, a = ba & 3;
+        const long r = rt + ty + 16 * a;
+        const long c = ct + 2 * tx + 32 * b;
+        const bool rv = AUX ? (r < m) : site_valid(L, r);
+        d2_t v;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            cv[e] = PAD ? site_valid(L, c + e) : true;
+            const bool cv = site_valid(L, c + e);
+            const bool valid = rv && cv;
+            double val = 0.0;
             if (FAST) {
-                cu0[e] = S.u0[c + e];
-                cu1[e] = S.u1[c + e];
-                cu2[e] = S.u2[c + e];
+                const double dx = R.u0[r] - S.u0[c + e], dy = R.u1[r] - S.u1[c + e], dz = R.u2[r] - S.u2[c + e];
+                const double q = dx * dx + dy * dy + dz * dz;
+                int iv;
+                const double y = ck_table_y(q, &iv, tbase);
+                const bool slow = valid && (unsigned)iv >= tn;   // padding lanes never ask for the exact pass
+                slowmask |= slow ? (1u << (ba * 2 + e)) : 0u;
+                val = ck_table_poly(lcoef, min(max(iv, 0), (int)tn - 1), y);
+            } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
+                if (valid)
+                    val = exact_entry_call(&mb, metric, nug, R.c0[r], R.c1[r], R.c2[r], S.c0[c + e], S.c1[c + e],
+                                           S.c2[c + e]);
+            }
+            if (AUX) {
+                // rows: prediction sites | z | zero padding; padded columns are zero
+                if (!rv) val = (r == m) ? z[c + e] : 0.0;
+                if (!cv) val = 0.0;
             } else {
-                cc0[e] = S.c0[c + e];
-                cc1[e] = S.c1[c + e];
-                cc2[e] = S.c2[c + e];
+                if (!valid) val = (r == c + e) ? 1.0 : 0.0;   // padding: identity
             }
+            v[e] = val;
         }
-        double zc[2] = {0.0, 0.0};
-        if (AUX && PAD) {
-            zc[0] = z[c];
-            zc[1] = z[c + 1];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const long r = rt + ty + 16 * a;
-            d2_t v;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                double val = 0.0;
-                const bool valid = PAD ? (R.v[a] && cv[e]) : true;
-                if (FAST) {
-                    const double dx = R.u0[a] - cu0[e], dy = R.u1[a] - cu1[e], dz = R.u2[a] - cu2[e];
-                    const double q = dx * dx + dy * dy + dz * dz;
-                    int iv;
-                    const double y = ck_table_y(q, &iv, tbase);
-                    const bool slow = valid && (unsigned)iv >= tn;   // q == 0 lands here too
-                    iv = min(max(iv, 0), (int)tn - 1);               // keep the lookup inside the table
-                    val = ck_table_poly(lcoef, iv, y);
-                    slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
-                } else if (__builtin_amdgcn_ballot_w64(valid) != 0ULL) {
-                    if (valid) val = exact_entry_call(&mb, metric, nug, R.c0[a], R.c1[a], R.c2[a], cc0[e], cc1[e], cc2[e]);
-                }
-                if (PAD) {
-                    if (AUX) {
-                        // rows: prediction sites | z | zero padding; padded columns are zero
-                        if (!R.v[a]) val = (r == m) ? zc[e] : 0.0;
-                        if (!cv[e]) val = 0.0;
-                    } else {
-                        if (!valid) val = (r == c + e) ? 1.0 : 0.0;   // padding: identity
-                    }
-                }
-                v[e] = val;
-            }
-            *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
-        }
+        *reinterpret_cast<d2_t*>(obase + (ty + 16 * a) * CK_NB + 2 * tx + 32 * b) = v;
     }
     return slowmask;
 }
@@ -223,20 +254,13 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
     const long rt = row0 + tile * 64;
     const int pr = AUX ? i_pred : (int)(rt >= L.n0p);
     const bool row_pad = AUX ? (rt + 64 > m) : range_has_padding(L, rt);
-    CkRowRegs rr;
+    double ru0[4], ru1[4], ru2[4];   // table path: chord vectors of this thread's four rows
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const long r = rt + ty + 16 * a;
-        rr.v[a] = AUX ? (r < m) : site_valid(L, r);
-        if (FAST) {
-            rr.u0[a] = R.u0[r];
-            rr.u1[a] = R.u1[r];
-            rr.u2[a] = R.u2[r];
-        } else {
-            rr.c0[a] = R.c0[r];
-            rr.c1[a] = R.c1[r];
-            rr.c2[a] = R.c2[r];
-        }
+        ru0[a] = FAST ? R.u0[r] : 0.0;
+        ru1[a] = FAST ? R.u1[r] : 0.0;
+        ru2[a] = FAST ? R.u2[r] : 0.0;
     }
     int loaded = -1, tbase = 0;
     unsigned tn = 1;
@@ -258,9 +282,9 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
         }
         unsigned slowmask;
         if (!FAST || row_pad || range_has_padding(L, ct))
-            slowmask = assemble_subtile<FAST, AUX, true>(mb, metric, lcoef, tbase, tn, rr, S, z, L, rt, ct, m, nug, obase, ty, tx);
+            slowmask = assemble_subtile_edge<FAST, AUX>(mb, metric, lcoef, tbase, tn, R, S, z, L, rt, ct, m, nug, obase, ty, tx);
         else
-            slowmask = assemble_subtile<FAST, AUX, false>(mb, metric, lcoef, tbase, tn, rr, S, z, L, rt, ct, m, nug, obase, ty, tx);
+            slowmask = assemble_subtile_interior(lcoef, tbase, tn, ru0, ru1, ru2, S, ct, obase, ty, tx);
         if (FAST && __builtin_amdgcn_ballot_w64(slowmask != 0u) != 0ULL)   // rare: hand the pairs to the exact pass
             worklist_append(wl, slowmask, (int)(rt + ty), 16, (int)(ct + 2 * tx));
     }
