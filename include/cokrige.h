@@ -164,8 +164,12 @@ int ck_vario_end(ck_handle* h);
 
 /* ---- diagnostics ------------------------------------------------------------- */
 /* Copy the locally owned part of Sigma / L back as a dense (N x N) lower triangle
- * (upper triangle zero-filled); small N only (tests). */
+ * (upper triangle zero-filled); small N only (tests).  Rows / columns are in the handle's INTERNAL
+ * site order: process 0 then process 1, each in the order ck_debug_site_order reports. */
 int ck_debug_get_lower(ck_handle* h, double* out_host, int64_t n);
+/* perm_out[j] = caller's index (within process k) of the site at internal position j.  Identity
+ * with option site_order = 0; a Hilbert-curve order with site_order = 1 (the default). */
+int ck_debug_site_order(ck_handle* h, int k, int64_t* perm_out, int64_t n_k);
 /* Raw lane/register -> (row, col) map of v_mfma_f64_16x16x4_f64: out[64*4*3] ints (row, col, k-map check). */
 int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,
@@ -178,10 +182,11 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
  * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local). */
 int ck_timings(ck_handle* h, double* out, int n);
-/* The assembly kernels evaluate the Matern correlation through a per-block table of log rho
- * over the squared chord (built on the device from the exact K_nu evaluator and verified against
- * it when the data are laid out).  Per block (0 = 11, 1 = 12, 2 = 22): whether the table passed
- * its check (else that block uses the exact evaluator), its size / range, its measured error. */
+/* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
+ * the squared chord (built on the device from the exact K_nu evaluator and verified against it
+ * when the data are laid out; error measure |table - C| / (|amp| max(rho, 1e-6)), gate 2e-13).
+ * Per block (0 = 11, 1 = 12, 2 = 22): whether the table passed its check (else the assembly uses
+ * the exact evaluator), its size / range, its measured error. */
 int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, double* q_lo, double* q_hi,
                   double* max_rel_err);
 /* Entries the table path deferred to the exact evaluator (pairs closer than the table's lower end
@@ -190,7 +195,16 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events;
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
- * of panel K (ck_factor, ck_predict); "gemm_variant" selects the GEMM tile structure (A/B tests). */
+ * of panel K (ck_factor, ck_predict); "gemm_variant" selects the GEMM tile structure (A/B tests);
+ * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and
+ * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
+ * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,
+ * less divergence in the exact evaluator).  Predictions, LOOCV results and variograms come back in the
+ * caller's order either way and agree to rounding (Sigma is permuted symmetrically).  What depends on
+ * the order: L itself (ck_debug_get_lower; ck_sample therefore insists on site_order = 0), and the
+ * index of the failing leading minor of a Sigma that is not positive definite -- ck_factor repeats such
+ * a factorisation in the caller's order to report numpy's index; ck_panel_* callers get the index in
+ * factorisation order. */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);
 /* Plain C -= A B^T on device buffers through the MFMA kernel (tests / microbenchmarks).
  * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), all row-major device doubles;

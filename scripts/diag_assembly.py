@@ -5,35 +5,10 @@ import numpy as np
 from sif_xco2_cokriging_amd import native, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-presort = len(sys.argv) > 2 and sys.argv[2] == "hilbert"
-
-
-def hilbert_perm(xy):
-    lo, hi = xy.min(0), xy.max(0)
-    g = np.minimum(((xy - lo) / np.maximum(hi - lo, 1e-300) * 65536).astype(np.int64), 65535)
-    x, y = g[:, 0].copy(), g[:, 1].copy()
-    d = np.zeros(len(xy), dtype=np.int64)
-    s = 32768
-    while s > 0:
-        rx = ((x & s) > 0).astype(np.int64)
-        ry = ((y & s) > 0).astype(np.int64)
-        d += s * s * ((3 * rx) ^ ry)
-        flip = (ry == 0) & (rx == 1)
-        x = np.where(flip, s - 1 - x, x)
-        y = np.where(flip, s - 1 - y, y)
-        swap = ry == 0
-        x, y = np.where(swap, y, x), np.where(swap, x, y)
-        s >>= 1
-    return np.argsort(d, kind="stable")
-
+site_order = 0 if (len(sys.argv) > 2 and sys.argv[2] == "caller") else 1   # "caller": keep the caller's site order
 
 for name, params in (("A", synth.SET_A), ("B", synth.SET_B)):
     pb = synth.conus_problem(n, params=params)
-    if presort:
-        for k in range(2):
-            pm = hilbert_perm(pb["coords"][k])
-            pb["coords"][k] = np.ascontiguousarray(pb["coords"][k][pm])
-            pb["values"][k] = np.ascontiguousarray(pb["values"][k][pm])
     for exact in (0, 1):
         h = native.Handle(0)
         pv = pb["params"]
@@ -42,6 +17,7 @@ for name, params in (("A", synth.SET_A), ("B", synth.SET_B)):
         for k in range(2):
             h.set_data(k, pb["coords"][k], pb["values"][k])
         h.set_option("exact_cov", exact)
+        h.set_option("site_order", site_order)
         h.assemble_joint()
         h.table_fallbacks(reset=True)
         h.assemble_joint()
@@ -50,5 +26,5 @@ for name, params in (("A", synth.SET_A), ("B", synth.SET_B)):
         if not exact:
             print(name, [h.table_info(b) for b in range(3)])
         N = 2 * n
-        print(f"set {name} exact={exact} n={n}: assemble {t:.2f} ms -> {8*N*(N+1)/2/t/1e6:.1f} GB/s")
+        print(f"set {name} exact={exact} site_order={site_order} n={n}: assemble {t:.2f} ms -> {8*N*(N+1)/2/t/1e6:.1f} GB/s")
         h.close()

@@ -16,7 +16,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/cokrige.h"
@@ -67,6 +69,13 @@ struct ck_handle {
     int64_t n0p = 0, nend = 0;    // internal order: process 0 in [0, n0), process 1 in [n0p, nend)
     int nK = 0;
     bool layout_ready = false;
+    // option "site_order": 1 = the sites of each process (and large sets of prediction points) are
+    // laid out along a Hilbert curve, so that the 64 rows / columns of an assembly tile are
+    // neighbours in space and the lanes of a wave look up neighbouring table intervals; 0 = the
+    // caller's order.  perm[k][j] = caller's index of the site at internal position j of process k.
+    int site_order = 1;
+    std::vector<int64_t> perm[2], pperm;
+    bool p_sorted = false;
     double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *z = nullptr;   // stacked sites / values (Npad)
     double* su = nullptr;               // chord vectors of the stacked sites (3 x Npad)
     double* pu = nullptr;               // chord vectors of the prediction sites (3 x mpad)
@@ -355,6 +364,51 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     return 0;
 }
 
+// Position along the Hilbert curve of order 16 through the unit square (x, y in [0, 65536)).
+static uint64_t hilbert_key(uint32_t x, uint32_t y) {
+    uint64_t d = 0;
+    for (uint32_t s = 32768; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += (uint64_t)s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {   // rotate the quadrant (only the bits below s matter from here on)
+            if (rx == 1) {
+                x = s - 1 - x;
+                y = s - 1 - y;
+            }
+            const uint32_t t = x;
+            x = y;
+            y = t;
+        }
+    }
+    return d;
+}
+
+// perm <- the indices 0..n-1 ordered along the Hilbert curve through the box [lo, hi]^2 of the
+// 2-column coordinates (stable: coincident sites keep the caller's order)
+static void hilbert_order(const double* xy, int64_t n, const double lo[2], const double hi[2],
+                          std::vector<int64_t>& perm) {
+    std::vector<std::pair<uint64_t, int64_t>> key((size_t)n);
+    const double sx = hi[0] > lo[0] ? 65536.0 / (hi[0] - lo[0]) : 0.0, sy = hi[1] > lo[1] ? 65536.0 / (hi[1] - lo[1]) : 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+        double fx = (xy[2 * k] - lo[0]) * sx, fy = (xy[2 * k + 1] - lo[1]) * sy;
+        fx = fx >= 0.0 ? (fx < 65535.0 ? fx : 65535.0) : 0.0;   // also catches NaN
+        fy = fy >= 0.0 ? (fy < 65535.0 ? fy : 65535.0) : 0.0;
+        key[(size_t)k] = {hilbert_key((uint32_t)fx, (uint32_t)fy), k};
+    }
+    std::stable_sort(key.begin(), key.end(),
+                     [](const std::pair<uint64_t, int64_t>& a, const std::pair<uint64_t, int64_t>& b) { return a.first < b.first; });
+    perm.resize((size_t)n);
+    for (int64_t k = 0; k < n; ++k) perm[(size_t)k] = key[(size_t)k].second;
+}
+
+static void bounding_box(const double* xy, int64_t n, double lo[2], double hi[2]) {
+    for (int64_t k = 0; k < n; ++k)
+        for (int d = 0; d < 2; ++d) {
+            lo[d] = fmin(lo[d], xy[2 * k + d]);
+            hi[d] = fmax(hi[d], xy[2 * k + d]);
+        }
+}
+
 // Decide the padded layout, upload sites / values, allocate the owned panels.
 static int ensure_layout(ck_handle* h) {
     if (h->layout_ready) return 0;
@@ -378,12 +432,23 @@ static int ensure_layout(ck_handle* h) {
         h->s2 = h->s0 + 2 * Np;
     }
     // stage coords -> device, transform
+    double blo[2] = {1e300, 1e300}, bhi[2] = {-1e300, -1e300};
+    for (int k = 0; k < h->n_procs; ++k) bounding_box(h->h_coords[k].data(), h->n[k], blo, bhi);
     std::vector<double> hc(2 * Np, 0.0), hz(Np, 0.0);
-    memcpy(hc.data(), h->h_coords[0].data(), 2 * n0 * 8);
-    memcpy(hz.data(), h->h_values[0].data(), n0 * 8);
-    if (n1) {
-        memcpy(hc.data() + 2 * h->n0p, h->h_coords[1].data(), 2 * n1 * 8);
-        memcpy(hz.data() + h->n0p, h->h_values[1].data(), n1 * 8);
+    for (int k = 0; k < h->n_procs; ++k) {
+        const int64_t nk = h->n[k], off = k == 0 ? 0 : h->n0p;
+        if (h->site_order) {
+            hilbert_order(h->h_coords[k].data(), nk, blo, bhi, h->perm[k]);
+        } else {
+            h->perm[k].resize((size_t)nk);
+            for (int64_t j = 0; j < nk; ++j) h->perm[k][(size_t)j] = j;
+        }
+        for (int64_t j = 0; j < nk; ++j) {
+            const int64_t e = h->perm[k][(size_t)j];
+            hc[2 * (off + j)] = h->h_coords[k][2 * e];
+            hc[2 * (off + j) + 1] = h->h_coords[k][2 * e + 1];
+            hz[off + j] = h->h_values[k][e];
+        }
     }
     double* d_tmp = nullptr;
     HIPCHK(hipMalloc((void**)&d_tmp, 2 * Np * 8));
@@ -393,18 +458,7 @@ static int ensure_layout(ck_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d_tmp));
     // squared bounding-box diagonal of the data sites (Euclidean table range)
-    double qbox = 0.0;
-    {
-        double lo0 = 1e300, hi0 = -1e300, lo1 = 1e300, hi1 = -1e300;
-        for (int64_t k = 0; k < h->nend; ++k) {
-            if (k >= n0 && k < h->n0p) continue;
-            lo0 = fmin(lo0, hc[2 * k]);
-            hi0 = fmax(hi0, hc[2 * k]);
-            lo1 = fmin(lo1, hc[2 * k + 1]);
-            hi1 = fmax(hi1, hc[2 * k + 1]);
-        }
-        qbox = (hi0 - lo0) * (hi0 - lo0) + (hi1 - lo1) * (hi1 - lo1);
-    }
+    const double qbox = (bhi[0] - blo[0]) * (bhi[0] - blo[0]) + (bhi[1] - blo[1]) * (bhi[1] - blo[1]);
     if (build_tables(h, qbox)) return -1;
     // panels
     if (h->sig.empty()) {
@@ -523,6 +577,7 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
+    bool fast_done = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
         HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
@@ -534,16 +589,20 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, false, h->d_blk, h->metric, 0, nullptr, 0, h->s0, layout_of(h), h->wl,
                                h->d_sigptr, nullptr);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));   // table kernel + exact pass; the count check below is host latency
         unsigned cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, h->wl.count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->fallback_total += cnt;
-        if (cnt <= h->wl.cap) break;   // else: too many out-of-table pairs for the list -> exact kernels
+        if (cnt <= h->wl.cap) {
+            fast_done = true;
+            break;
+        }   // else: too many out-of-table pairs for the list -> exact kernels
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(long long), h->stream));
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipEventSynchronize(h->ev1));
+    if (!fast_done) HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[0] = ms;
@@ -708,11 +767,7 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     return 0;
 }
 
-extern "C" int ck_factor(ck_handle* h, int64_t* info) {
-    CHKH(h);
-    if (h->world != 1) return fail("ck_factor is the single-process form; drive ck_panel_* for world > 1");
-    if (!h->assembled) return fail("ck_assemble_joint has not been called");
-    if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
+static int factor_sweep(ck_handle* h) {
     h->gemm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (!h->lookahead) {
@@ -739,7 +794,27 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
+    return 0;
+}
+
+extern "C" int ck_factor(ck_handle* h, int64_t* info) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_factor is the single-process form; drive ck_panel_* for world > 1");
+    if (!h->assembled) return fail("ck_assemble_joint has not been called");
+    if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
+    if (factor_sweep(h)) return -1;
     if (ck_factor_info(h, info)) return -1;
+    if (*info != 0 && h->site_order) {
+        // Not positive definite.  numpy names the failing leading minor of Sigma in the CALLER's
+        // order (cho_factor, joint_prediction.py:68-69, raises LinAlgError): redo the factorisation in that
+        // order so that the reported index is the reference's.  The handle stays in site_order 0.
+        h->site_order = 0;
+        h->layout_ready = false;
+        h->assembled = false;
+        if (ck_assemble_joint(h)) return -1;
+        if (factor_sweep(h)) return -1;
+        if (ck_factor_info(h, info)) return -1;
+    }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[1] = ms;
@@ -748,8 +823,7 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     return 0;
 }
 
-extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t m) {
-    CHKH(h);
+static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m, bool may_sort) {
     if (ensure_layout(h)) return -1;
     if (i < 0 || i >= h->n_procs) return fail("process index out of range");
     if (m < 0 || (m > 0 && !pcoords)) return fail("bad pcoords");
@@ -778,6 +852,21 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
     h->i_pred = i;
     h->m = m;
     h->mpad = mpad;
+    // large sets of prediction points are laid out along the Hilbert curve like the data sites
+    // (site_order above); ck_aux_finish hands the results back in the caller's order
+    std::vector<double> sorted;
+    h->p_sorted = may_sort && h->site_order && m >= 256;
+    if (h->p_sorted) {
+        double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+        bounding_box(pcoords, m, lo, hi);
+        hilbert_order(pcoords, m, lo, hi, h->pperm);
+        sorted.resize((size_t)(2 * m));
+        for (int64_t j = 0; j < m; ++j) {
+            sorted[2 * j] = pcoords[2 * h->pperm[(size_t)j]];
+            sorted[2 * j + 1] = pcoords[2 * h->pperm[(size_t)j] + 1];
+        }
+        pcoords = sorted.data();   // alive until the event synchronisation at the end of this function
+    }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
     if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
@@ -805,6 +894,11 @@ extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t 
     return 0;
 }
 
+extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t m) {
+    CHKH(h);
+    return aux_begin_impl(h, i, pcoords, m, true);
+}
+
 extern "C" int ck_aux_finish(ck_handle* h, double* pred, double* pred_err) {
     CHKH(h);
     if (h->mpad <= 0) return fail("ck_aux_begin has not been called");
@@ -813,11 +907,21 @@ extern "C" int ck_aux_finish(ck_handle* h, double* pred, double* pred_err) {
     ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, h->m, h->m, c0, h->d_pred, h->d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    if (h->m > 0) {
+    if (h->m > 0 && !h->p_sorted) {
         HIPCHK(hipMemcpyAsync(pred, h->d_pred, h->m * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(pred_err, h->d_err, h->m * 8, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->m > 0 && h->p_sorted) {   // back to the caller's order
+        std::vector<double> tp((size_t)h->m), te((size_t)h->m);
+        HIPCHK(hipMemcpyAsync(tp.data(), h->d_pred, h->m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(te.data(), h->d_err, h->m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t j = 0; j < h->m; ++j) {
+            pred[h->pperm[(size_t)j]] = tp[(size_t)j];
+            pred_err[h->pperm[(size_t)j]] = te[(size_t)j];
+        }
+    }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[4] = ms;
@@ -872,6 +976,8 @@ extern "C" int ck_sample(ck_handle* h, const double* noise, double* out, int64_t
     if (h->world != 1) return fail("ck_sample is the single-process form");
     if (!h->factored) return fail("ck_factor has not been called");
     if (n != h->N) return fail("n must equal the number of observations");
+    if (h->site_order)
+        return fail("ck_sample: L eps depends on the order of the sites; set option site_order = 0 before assembling");
     const int64_t Np = h->Npad, n0 = h->n[0], gap = h->n0p - n0;
     std::vector<double> hv(Np, 0.0), ho(Np);
     memcpy(hv.data(), noise, n0 * 8);
@@ -911,7 +1017,7 @@ extern "C" int ck_loocv(ck_handle* h, int i, double* pred, double* pred_err) {
     if (m <= 0) return 0;
     // reuse the aux machinery: allocate as for m prediction points (coordinates unused)
     std::vector<double> dummy(2 * m, 0.0);
-    if (ck_aux_begin(h, i, dummy.data(), m)) return -1;
+    if (aux_begin_impl(h, i, dummy.data(), m, false)) return -1;
     HIPCHK(hipMemsetAsync(h->aux, 0, (size_t)h->mpad * h->Npad * 8, h->stream));
     ck_launch_loo_rows(h->stream, h->aux, h->mpad, m, i == 0 ? 0 : h->n0p, h->z, h->Npad);
     HIPCHK(hipGetLastError());
@@ -924,10 +1030,11 @@ extern "C" int ck_loocv(ck_handle* h, int i, double* pred, double* pred_err) {
     HIPCHK(hipMemcpyAsync(s2.data(), h->d_err, m * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const double* zi = h->h_values[i].data();
-    for (int64_t q = 0; q < m; ++q) {
-        pred[q] = zi[q] - s1[q] / s2[q];
+    for (int64_t q = 0; q < m; ++q) {   // q: internal position; results go to the caller's index
+        const int64_t x = h->perm[i][(size_t)q];
+        pred[x] = zi[x] - s1[q] / s2[q];
         const double e = sqrt(1.0 / s2[q]);
-        pred_err[q] = (e == e) ? e : 0.0;
+        pred_err[x] = (e == e) ? e : 0.0;
     }
     return 0;
 }
@@ -1172,6 +1279,15 @@ extern "C" int ck_vario_end(ck_handle* h) {
 // ---------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------
+extern "C" int ck_debug_site_order(ck_handle* h, int k, int64_t* perm_out, int64_t n_k) {
+    CHKH(h);
+    if (k < 0 || k >= h->n_procs) return fail("process index out of range");
+    if (ensure_layout(h)) return -1;
+    if (n_k != h->n[k]) return fail("n_k must equal the number of observations of process k");
+    for (int64_t j = 0; j < n_k; ++j) perm_out[j] = h->perm[k][(size_t)j];
+    return 0;
+}
+
 extern "C" int ck_debug_get_lower(ck_handle* h, double* out, int64_t n) {
     CHKH(h);
     if (!h->assembled) return fail("nothing assembled");
@@ -1275,6 +1391,12 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
         h->lookahead = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "site_order")) {   // 0: caller's order | 1: Hilbert order (see ck_handle::site_order)
+        if (h->layout_ready && (value != 0) != (h->site_order != 0))
+            return fail("site_order must be set before the data are laid out (first assemble / predict)");
+        h->site_order = value != 0;
         return 0;
     }
     if (!strcmp(name, "exact_cov")) {   // 1: per-entry Bessel evaluation instead of the tables

@@ -59,6 +59,7 @@ _PROTOS = {
     "ck_vario_bin": [c_void_p, c_double, _dp, c_int, c_int, _dp, POINTER(c_int64)],
     "ck_vario_end": [c_void_p],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
+    "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
@@ -325,6 +326,12 @@ class Handle:
     def debug_get_lower(self, n):
         out = np.empty((n, n))
         _chk(lib().ck_debug_get_lower(self._h, _p(out), int(n)))
+        return out
+
+    def debug_site_order(self, k, n_k):
+        """perm[j] = caller's index (within process k) of the site at internal position j."""
+        out = np.empty(int(n_k), dtype=np.int64)
+        _chk(lib().ck_debug_site_order(self._h, int(k), out.ctypes.data_as(POINTER(c_int64)), int(n_k)))
         return out
 
     def mfma_probe(self):

@@ -38,6 +38,7 @@ class BivariateRandomField:
         h = native.Handle(device)
         configure_handle(h, model)
         h.set_metric(native.METRIC_EUCLID)
+        h.set_option("site_order", 0)   # z = L eps: the draw for a given eps depends on the order of the sites
         zero = np.zeros(grid.count)
         h.set_data(0, xy, zero)
         h.set_data(1, xy, zero)

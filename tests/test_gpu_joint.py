@@ -134,30 +134,46 @@ def test_gemm_nt_mfma(native, variant):
     h.set_option("gemm_variant", 4)
 
 
-def _assembled(native, params, coords, values, metric, exact=False):
+def _assembled(native, params, coords, values, metric, exact=False, site_order=None):
     h, p = handle_for(native, params, metric)
     for k in range(p.n_procs):
         h.set_data(k, coords[k], values[k])
     if exact:
         h.set_option("exact_cov", 1)
+    if site_order is not None:
+        h.set_option("site_order", site_order)
     h.assemble_joint()
     return h, p
 
 
+def _internal_index(h, coords):
+    """Stacked caller indices in the handle's internal order (ck_debug_site_order)."""
+    n0 = len(coords[0])
+    return np.concatenate([h.debug_site_order(0, n0), n0 + h.debug_site_order(1, len(coords[1]))])
+
+
+@pytest.mark.parametrize("site_order", [0, 1])
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("tag", ["A", "R"])
-def test_assemble_and_factor_vs_oracle(native, exact, tag):
-    """Sigma entry by entry (tabulated and per-entry Bessel paths), then L against numpy."""
+def test_assemble_and_factor_vs_oracle(native, exact, tag, site_order):
+    """Sigma entry by entry (tabulated and per-entry Bessel paths), then L against numpy -- in the
+    caller's order (site_order 0) and in the library's Hilbert order (1: Sigma permuted symmetrically)."""
     g = load_golden("joint_solve")
     coords = [g[f"coords0_{tag}"], g[f"coords1_{tag}"]]
     values = [g[f"values0_{tag}"], g[f"values1_{tag}"]]
-    h, p = _assembled(native, g[f"params_{tag}"], coords, values, HAV, exact=exact)
+    h, p = _assembled(native, g[f"params_{tag}"], coords, values, HAV, exact=exact, site_order=site_order)
     if not exact:
         for b in range(3):
             ti = h.table_info(b)
             assert ti["enabled"] and ti["max_rel_err"] < 2e-13, ti
     N = 400
     S = orc.joint_cov(p, coords, HAV)
+    idx = _internal_index(h, coords)
+    if site_order == 0:
+        assert np.array_equal(idx, np.arange(N))
+    else:
+        assert sorted(idx.tolist()) == list(range(N)) and not np.array_equal(idx, np.arange(N))
+    S = S[np.ix_(idx, idx)]
     low = h.debug_get_lower(N)
     if exact:
         # 5e-13 relative; entries below 1e-30 (e^-70 of the variance) only to 1e-30 absolute
@@ -208,11 +224,39 @@ def test_kat_simulation_experiment(native):
     assert np.max(np.abs(err - g["pred_err_uni"])) < 1e-6
 
 
-def test_not_positive_definite_reports_minor(native):
+@pytest.mark.parametrize("site_order", [0, 1])
+def test_not_positive_definite_reports_minor(native, site_order):
+    """numpy's index of the failing leading minor -- also when the library factorised in its own
+    (Hilbert) order first: ck_factor repeats the factorisation in the caller's order to report it."""
     g = load_golden("joint_not_pd")
-    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], HAV)
+    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], HAV,
+                      site_order=site_order)
     info = h.factor()
     assert info == int(g["minor"])
+
+
+def test_site_order_invariance(native):
+    """Predictions and LOOCV results do not depend on the internal site order (Sigma is permuted
+    symmetrically); prediction points come back in the caller's order; ck_sample refuses the Hilbert order."""
+    from sif_xco2_cokriging_amd import synth
+    pb = synth.conus_problem(700, params=synth.SET_A, seed=5)
+    pb["pcoords"] = pb["pcoords"][::9]   # 982 points: enough for the library to sort them (>= 256)
+    out = []
+    for so in (0, 1):
+        h, p = _assembled(native, pb["params"], pb["coords"], pb["values"], HAV, site_order=so)
+        assert h.factor() == 0
+        pr = [h.predict(i, pb["pcoords"]) for i in (0, 1)]
+        cv = [h.loocv(i, 700) for i in (0, 1)]
+        out.append((pr, cv))
+        if so == 1:
+            with pytest.raises(RuntimeError, match="site_order"):
+                h.sample(np.zeros(1400))
+            with pytest.raises(RuntimeError, match="site_order"):
+                h.set_option("site_order", 0)
+        h.close()
+    for i in (0, 1):
+        for a, b in zip(out[0][0][i] + out[0][1][i], out[1][0][i] + out[1][1][i]):
+            assert rel(a, b) < 1e-9
 
 
 def test_predictor_class_api(native):
