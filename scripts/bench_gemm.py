@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sif_xco2_cokriging_amd import native
 
-M, N, K = 16384, 8192, 512
+M, N, K = (int(x) for x in os.environ.get("CK_GEMM_MNK", "16384,8192,512").split(","))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 A = torch.randn(M, K, dtype=torch.float64, device=dev)

@@ -41,6 +41,7 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+    flags += os.environ.get("CK_EXTRA_HIPCC_FLAGS", "").split()   # kernel experiments (-D...); use with --force
 
     def compile_one(src):
         path = os.path.join(CSRC, src)

@@ -521,6 +521,9 @@ __device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, co
     }
     __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
     __syncthreads();
+#ifdef CK_EXPERIMENT_PHASE
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) __builtin_amdgcn_s_sleep(32);   // HW_ID.wave_id parity
+#endif
 
     const int nst = K / GEMM_BK;
     for (int st = 0; st < nst; ++st) {
@@ -600,6 +603,143 @@ __global__ __launch_bounds__(256, 2) void k_syrk_panels_s(double* const* __restr
     gemm_tile_s<0>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
+// ---------------------------------------------------------------------------------------
+// 128 x 128 tile, 8 waves of 64 x 32, two workgroups per CU (option "gemm_variant" = 5)
+// ---------------------------------------------------------------------------------------
+// Same tile, LDS image and K pipeline as gemm_tile_s, but each wave owns a 64 x 32 quarter-strip
+// (8 accumulator tiles = 64 VGPRs instead of 128), so the kernel fits 128 VGPRs and FOUR waves
+// share a SIMD: while one waits at the per-chunk barrier or on its fragment reads, three others
+// can feed the MFMA pipe (with gemm_tile_s it is one other).
+template <int DUMMY>
+__device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
+                                            const double* __restrict__ B, long ldb, long r0, long c0, int K,
+                                            char* lds) {
+    constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
+    constexpr int STAGE = 256 * 128;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int li = lane & 15, g = lane >> 4;
+
+    const char* Ab = reinterpret_cast<const char*>(A + r0 * lda);
+    const char* Bb = reinterpret_cast<const char*>(B + c0 * ldb);
+    double* Cb = C + r0 * ldc + c0;
+    // staging: chunk (row = tid >> 3 (+64 u), pair p = tid & 7) -> slot p ^ ((row >> 1) & 7); row + 64 u keeps the swizzle
+    const int srow = tid >> 3, sp = tid & 7;
+    const unsigned a_src0 = (unsigned)(srow * (int)lda + sp * 2) * 8u;
+    const unsigned b_src0 = (unsigned)(srow * (int)ldb + sp * 2) * 8u;
+    const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
+    const long a_step = 64 * lda * 8, b_step = 64 * ldb * 8;   // bytes, wave-uniform
+    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * 32 + li) * 8u;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int slot = (4 * kb + g) ^ (li >> 1);
+        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
+        b_rd[kb] = BOFF + (wn * 32 + li) * 128 + slot * 16;
+    }
+
+    d2_t ra[2], rb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        ra[u] = *reinterpret_cast<const d2_t*>(Ab + u * a_step + a_src0);
+        rb[u] = *reinterpret_cast<const d2_t*>(Bb + u * b_step + b_src0);
+    }
+    d4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        *reinterpret_cast<d2_t*>(lds + s_dst0 + u * 8192) = -ra[u];
+        *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * 8192) = rb[u];
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
+    __syncthreads();
+
+    const int nst = K / GEMM_BK;
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1 < nst);
+        if (more) {
+            const long k0 = (long)(st + 1) * (GEMM_BK * 8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ra[u] = *reinterpret_cast<const d2_t*>(Ab + (k0 + u * a_step) + a_src0);
+                rb[u] = *reinterpret_cast<const d2_t*>(Bb + (k0 + u * b_step) + b_src0);
+            }
+        }
+        const char* sb = lds + cur * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            d2_t af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* nx = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                *reinterpret_cast<d2_t*>(nx + s_dst0 + u * 8192) = -ra[u];
+                *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * 8192) = rb[u];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
+        }
+}
+
+__global__ __launch_bounds__(512, 4) void k_gemm_nt_e(double* __restrict__ C, long ldc, const double* __restrict__ A,
+                                                       long lda, const double* __restrict__ B, long ldb, int tiles_m,
+                                                       int tiles_n, int K, int lower, long diag_off, long sC, long sA,
+                                                       long sB) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if (lower && r0 + 127 + diag_off < c0) return;
+    const long y = blockIdx.y;
+    gemm_tile_e<0>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
+}
+
+__global__ __launch_bounds__(512, 4) void k_syrk_panels_e(double* const* __restrict__ sigptr,
+                                                           const double* __restrict__ P, int K, int J0, int Jstep,
+                                                           long Npad) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = J0 + (int)blockIdx.y * Jstep;
+    const long M = Npad - (long)J * CK_NB;
+    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if (r0 + 127 < c0) return;
+    const double* A = P + (long)(J - K) * CK_NB * CK_NB;
+    gemm_tile_e<0>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
+}
+
 // plain (optionally batched over blockIdx.y) form
 template <int WN, int VAR>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long ldc, const double* __restrict__ A,
@@ -655,7 +795,13 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
                        int64_t sC, int64_t sA, int64_t sB) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
     const int v = g_ck_gemm_variant;
-    if (v == 4 && N % 128 == 0) {
+    if (v == 5 && N % 128 == 0) {
+        const int tm = (int)(M / 128), tn = (int)(N / 128);
+        k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
+                                                             sC, sA, sB);
+        return;
+    }
+    if ((v == 4 || v == 5) && N % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_s<<<dim3(tm * tn, batch), dim3(256), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
                                                              sC, sA, sB);
@@ -700,6 +846,11 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
     if (nJ <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
+    if (g_ck_gemm_variant == 5) {
+        k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
+                                                                                      Npad);
+        return;
+    }
     if (g_ck_gemm_variant == 4) {
         k_syrk_panels_s<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(256), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
