@@ -88,6 +88,12 @@ int ck_cov_dense(ck_handle* h, int i, int j, const double* A_host, int64_t a, co
                  int use_nugget, double* out_host);
 /* the same at given lags h[n] (MultivariateMatern.covariance / cross_covariance on an array). */
 int ck_cov_lags(ck_handle* h, int i, int j, const double* lags_host, int64_t n, int use_nugget, double* out_host);
+/* Model (cross-)variograms row by row -- the "fit" column of MultivariateMatern._map_fit and the
+ * curves of variograms() / FittedVariogram (src/model.py:209-260, 330-331): row r has process pair
+ * (i[r], j[r]) and lag h[r]; kind 0: semivariance(i, h) if i == j else cross_semivariance(i, j, h);
+ * kind 1 ("covariogram"): covariance(i, h) incl. nugget at h == 0 / cross_covariance(i, j, h). */
+int ck_model_variogram(ck_handle* h, const int32_t* i_host, const int32_t* j_host, const double* lags_host, int64_t n,
+                       int kind, double* out_host);
 
 /* ---- joint (global) cokriging: src/joint_prediction.py:35-153 --------------- */
 /* K1: assemble the lower block triangle of Sigma = [[C11, C12], [C12^T, C22]] for the

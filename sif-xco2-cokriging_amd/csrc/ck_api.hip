@@ -559,6 +559,40 @@ extern "C" int ck_cov_lags(ck_handle* h, int i, int j, const double* lags, int64
     return 0;
 }
 
+extern "C" int ck_model_variogram(ck_handle* h, const int32_t* pi, const int32_t* pj, const double* lags, int64_t n,
+                                  int kind, double* out) {
+    CHKH(h);
+    if (!h->model_set) return fail("ck_set_model has not been called");
+    if (kind != 0 && kind != 1) return fail("kind must be 0 (semivariogram) or 1 (covariogram)");
+    if (n <= 0) return 0;
+    if (!pi || !pj || !lags || !out) return fail("null array");
+    for (int64_t r = 0; r < n; ++r)
+        if (pi[r] < 0 || pj[r] < 0 || pi[r] >= h->n_procs || pj[r] >= h->n_procs)
+            return fail("process index out of range in row " + std::to_string(r));
+    // sill of the cross-semivariogram: nansum(sigma^2 + nugget) / 2 over the parameter arrays (model.py:219-221)
+    double sill = h->blk[0].amp + h->blk[0].nugget;
+    if (h->n_procs == 2) sill = 0.5 * (sill + (h->blk[2].amp + h->blk[2].nugget));
+    else sill = 0.5 * sill;
+    int *di = nullptr, *dj = nullptr;
+    double *dl = nullptr, *dO = nullptr;
+    HIPCHK(hipMalloc((void**)&di, n * 4));
+    HIPCHK(hipMalloc((void**)&dj, n * 4));
+    HIPCHK(hipMalloc((void**)&dl, n * 8));
+    HIPCHK(hipMalloc((void**)&dO, n * 8));
+    HIPCHK(hipMemcpyAsync(di, pi, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dj, pj, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dl, lags, n * 8, hipMemcpyHostToDevice, h->stream));
+    ck_launch_model_variogram(h->stream, h->d_blk, sill, kind, di, dj, dl, n, dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(di);
+    (void)hipFree(dj);
+    (void)hipFree(dl);
+    (void)hipFree(dO);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // joint path
 // ---------------------------------------------------------------------------------------

@@ -394,6 +394,35 @@ void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, c
 }
 
 
+// Model (cross-)variograms row by row (src/model.py:209-237): row r has process pair (pi[r], pj[r])
+// and lag h[r].  kind 0: semivariance sigma_i^2 (1 - rho) + nugget_i (i == j), sill - C_ij (i != j,
+// sill = mean of the two marginal sills, :219-221); kind 1: covariance incl. nugget / cross-covariance.
+__global__ void k_model_variogram(const CkMatern* __restrict__ blk, double sill, int kind,
+                                  const int* __restrict__ pi, const int* __restrict__ pj,
+                                  const double* __restrict__ lags, long n, double* __restrict__ out) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int i = pi[r], j = pj[r];
+    const CkMatern& m = blk[i + j];
+    const double h = fabs(lags[r]);   // model.py:373 takes |h|
+    double v;
+    if (kind == 1) {
+        v = ck_cov_entry(m, h, i == j);
+    } else if (i == j) {
+        const double rho = h == 0.0 ? 1.0 : ck_matern_rho_scaled(m, m.sqrt2nu * (h / m.len_scale));
+        v = m.amp * (1.0 - rho) + m.nugget;
+    } else {
+        v = sill - ck_cov_entry(m, h, 0);
+    }
+    out[r] = v;
+}
+
+void ck_launch_model_variogram(hipStream_t s, const CkMatern* blk, double sill, int kind, const int* pi,
+                               const int* pj, const double* lags, int64_t n, double* out) {
+    if (n <= 0) return;
+    k_model_variogram<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(blk, sill, kind, pi, pj, lags, n, out);
+}
+
 // =========================================================================================
 // Tabulated fast path (ck_math.h "Tabulated correlation")
 // =========================================================================================

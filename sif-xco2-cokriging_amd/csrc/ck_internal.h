@@ -60,6 +60,8 @@ void ck_launch_assemble_fix(hipStream_t s, bool aux_rows, const CkMatern* blk, i
 void ck_launch_cov_dense(hipStream_t s, const CkMatern* blk_ij, int metric, int add_nugget, int mode,
                          const double* a0, const double* a1, const double* a2, int64_t a, const double* b0,
                          const double* b1, const double* b2, int64_t b, double* out);
+void ck_launch_model_variogram(hipStream_t s, const CkMatern* blk, double sill, int kind, const int* pi,
+                               const int* pj, const double* lags, int64_t n, double* out);
 void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, const double* lags, int64_t n,
                         double* out);
 

@@ -4,13 +4,18 @@ attribute and method names the notebooks use.  The numbers come from the HIP
 library (``ck_cov_lags``): distance -> Matern auto/cross-covariance with a
 device K_nu; nothing is evaluated in numpy/scipy here.
 
-Not mirrored (out of the hot path): ``fit`` and
-``FittedVariogram``.
+``fit`` (composite weighted least squares, src/model.py:277-317) keeps
+the reference's optimiser call -- scipy L-BFGS-B with its finite-difference gradient -- and
+evaluates the model variograms of every cost-function call in ONE device launch
+(``ck_model_variogram``).
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 import pandas as pd
+from scipy.optimize import minimize
 
 from . import native
 
@@ -175,3 +180,84 @@ class MultivariateMatern:
         """src/model.py:215-222."""
         sill = 0.5 * np.nansum(self.params.sigma.values ** 2 + self.params.nugget.values)
         return sill - self.cross_covariance(i, j, h)
+
+    def get_variogram(self, i: int, j: int, h, kind: str) -> pd.DataFrame:
+        """src/model.py:224-237."""
+        h = np.asarray(h, dtype=np.float64)
+        v = self._handle().model_variogram(i, j, h, kind="covariogram" if kind == "covariogram" else "semivariogram")
+        df = pd.DataFrame({"distance": h, "variogram": v, "i": i, "j": j})
+        return df.set_index(["i", "j", df.index])
+
+    def variograms(self, h, kind: str = "semivariogram") -> pd.DataFrame:
+        """Modelled variograms and cross-variogram(s) at the given lags (src/model.py:239-248)."""
+        return pd.concat([self.get_variogram(i, j, h, kind)
+                          for i in range(self.n_procs) for j in range(self.n_procs) if i <= j])
+
+    @staticmethod
+    def _weighted_least_squares(ydata: np.ndarray, yfit: np.ndarray, bin_counts: np.ndarray) -> float:
+        """Cressie (1985) weighted least squares with the reference's handling of fit == 0
+        (src/model.py:250-264)."""
+        ydata, yfit, bin_counts = (np.asarray(a, dtype=np.float64) for a in (ydata, yfit, bin_counts))
+        zero = yfit == 0.0
+        wls = np.zeros_like(yfit)
+        wls[zero] = bin_counts[zero] * ydata[zero] ** 2
+        nz = ~zero
+        wls[nz] = bin_counts[nz] * ((ydata[nz] - yfit[nz]) / yfit[nz]) ** 2
+        return np.sum(wls)
+
+    def _map_fit(self, df_vario: pd.DataFrame) -> pd.DataFrame:
+        """New ``fit`` column: the model semivariogram at ``bin_center`` for every (i, j) group
+        (src/model.py:266-275), all groups in one device launch; rows come back grouped by (i, j)
+        in sorted order like ``groupby(level=[0, 1]).apply``."""
+        df = df_vario.sort_index(level=[0, 1], sort_remaining=False, kind="stable").copy()
+        i = df.index.get_level_values(0).values.astype(np.int32)
+        j = df.index.get_level_values(1).values.astype(np.int32)
+        lo, hi = np.minimum(i, j), np.maximum(i, j)   # cross-semivariance is symmetric (:216-218)
+        df["fit"] = self._handle().model_variogram(lo, hi, df["bin_center"].values.astype(np.float64))
+        return df
+
+    def _composite_wls(self, p, df_vario: pd.DataFrame) -> float:
+        """Composite WLS cost (src/model.py:277-283, 389-391)."""
+        self.params.set_values(p)
+        df = self._map_fit(df_vario)
+        ydata, yfit, counts = df[["bin_mean", "fit", "bin_count"]].T.values.astype(np.float64)
+        nz = yfit != 0.0
+        return np.sum(counts[nz] * ((ydata[nz] - yfit[nz]) / yfit[nz]) ** 2)
+
+    def fit(self, estimate, guess: MaternParams = None):
+        """Fit the parameters to the empirical (cross-)semivariograms simultaneously by composite
+        weighted least squares -- same flow, optimiser and warning as src/model.py:285-317."""
+        if estimate.config.n_procs != self.n_procs:
+            raise ValueError("Number of theoretical processes different from empirical processes.")
+        if guess is None:
+            init_params = self.params.reset_values().get_values()
+        else:
+            init_params = self.params.get_values()
+            self.params.set_bounds(**{p.name: p.bounds for p in guess._params})
+        bounds = self.params.get_bounds()
+        optim_result = minimize(self._composite_wls, init_params, args=(estimate.df,), method="L-BFGS-B", bounds=bounds)
+        if optim_result.success == False:   # noqa: E712  (as the reference)
+            warnings.warn("ERROR: optimization did not converge.")
+        self.params.set_values(optim_result.x)
+        self.fit_result = FittedVariogram(self, estimate, optim_result.fun)
+        return self
+
+
+class FittedVariogram:
+    """Model parameters and theoretical variogram for the corresponding empirical variogram
+    (src/model.py:320-347)."""
+
+    def __init__(self, model: MultivariateMatern, estimate, cost: float) -> None:
+        self.config = estimate.config
+        self.timestamp = estimate.timestamp
+        self.timedeltas = estimate.timedeltas
+        self.df_empirical = estimate.df
+        h = np.linspace(0, self.df_empirical["bin_center"].max(), 100)
+        self.df_theoretical = model.variograms(h)
+        self.params = model.params
+        self.cost = cost
+        self.cs_valid = self.cs_check()
+
+    def cs_check(self):
+        """Placeholder in the reference as well (src/model.py:337-347): always None."""
+        return None

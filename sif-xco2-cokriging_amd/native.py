@@ -39,6 +39,7 @@ _PROTOS = {
     "ck_distance_dense": [c_void_p, _dp, c_int64, _dp, c_int64, _dp],
     "ck_cov_dense": [c_void_p, c_int, c_int, _dp, c_int64, _dp, c_int64, c_int, _dp],
     "ck_cov_lags": [c_void_p, c_int, c_int, _dp, c_int64, c_int, _dp],
+    "ck_model_variogram": [c_void_p, POINTER(c_int32), POINTER(c_int32), _dp, c_int64, c_int, _dp],
     "ck_assemble_joint": [c_void_p],
     "ck_factor": [c_void_p, POINTER(c_int64)],
     "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
@@ -220,6 +221,16 @@ class Handle:
         h = _f64(h)
         out = np.empty(h.shape)
         _chk(lib().ck_cov_lags(self._h, int(i), int(j), _p(h.ravel()), h.size, int(bool(use_nugget)), _p(out)))
+        return out
+
+    def model_variogram(self, i, j, h, kind="semivariogram"):
+        """Row-wise model (cross-)variogram values (src/model.py:209-237) in one launch."""
+        h = _f64(h).ravel()
+        ii = np.ascontiguousarray(np.broadcast_to(np.asarray(i, dtype=np.int32), h.shape))
+        jj = np.ascontiguousarray(np.broadcast_to(np.asarray(j, dtype=np.int32), h.shape))
+        out = np.empty(h.shape)
+        _chk(lib().ck_model_variogram(self._h, ii.ctypes.data_as(POINTER(c_int32)), jj.ctypes.data_as(POINTER(c_int32)),
+                                      _p(h), h.size, 1 if kind == "covariogram" else 0, _p(out)))
         return out
 
     # -- joint path -------------------------------------------------------------------------

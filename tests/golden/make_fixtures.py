@@ -407,6 +407,70 @@ def fixture_sim():
          noise=np.random.default_rng(7).standard_normal(2 * grid.count))
 
 
+def fixture_fit():
+    """MultivariateMatern.fit (src/model.py:285-317): composite WLS fit of the three empirical
+    (cross-)semivariograms of an exact bivariate Matern draw, default start and a `guess` start;
+    plus the cost function at probe parameter vectors (independent of the optimiser's path)."""
+    truth = [0.9, 0.7, 0.8, 1.1, 1.5, 380.0, 420.0, 450.0, 0.03, 0.02, -0.45]
+    mod_t = make_model(truth)
+    rng = np.random.default_rng(701)
+    c0, c1 = conus_points(rng, 700), conus_points(rng, 600)
+    c1[:150] = c0[:150]
+    mf = make_mf([c0, c1], [np.zeros(700), np.zeros(600)])
+    pred = joint_prediction.Predictor(mod_t, mf)
+    S = pred._joint_cov()
+    z = np.linalg.cholesky(S) @ rng.standard_normal(1300)
+    v0, v1 = z[:700], z[700:]
+    mf = make_mf([c0, c1], [v0, v1], coords_all=[c0, c1], values_all=[v0, v1])
+    cfg = fields.VarioConfig(1500.0, 30)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est = mf.empirical_variograms(cfg)
+    out = dict(truth=np.array(truth), coords0=c0, coords1=c1, values0=v0, values1=v1)
+    for (i, j) in ((0, 0), (0, 1), (1, 1)):
+        g = est.df.xs((i, j), level=("i", "j"))
+        out[f"centers_{i}{j}"] = g["bin_center"].values.astype(float)
+        out[f"means_{i}{j}"] = g["bin_mean"].values.astype(float)
+        out[f"counts_{i}{j}"] = g["bin_count"].values.astype(np.int64)
+    # cost function at probe vectors
+    mod = model.MultivariateMatern(n_procs=2)
+    bounds = np.array([list(b) for b in mod.params.get_bounds()], dtype=float)
+    prng = np.random.default_rng(702)
+    probes = [mod.params.reset_values().get_values().astype(float), np.array(truth)]
+    for _ in range(6):
+        probes.append(bounds[:, 0] + prng.random(11) * (bounds[:, 1] - bounds[:, 0]))
+    probes = np.array(probes)
+    out["probes"] = probes
+    out["probe_cost"] = np.array([mod._composite_wls(p.copy(), est.df) for p in probes])
+    # default fit
+    mod = model.MultivariateMatern(n_procs=2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mod.fit(est)
+    out["fit_x"] = mod.params.get_values().astype(float)
+    out["fit_cost"] = np.array(mod.fit_result.cost)
+    out["fit_warned"] = np.array(int(any("did not converge" in str(x.message) for x in w)))
+    th = mod.fit_result.df_theoretical
+    out["theo_distance"] = th["distance"].values.astype(float)
+    out["theo_variogram"] = th["variogram"].values.astype(float)
+    out["theo_i"] = th.index.get_level_values("i").values.astype(np.int64)
+    out["theo_j"] = th.index.get_level_values("j").values.astype(np.int64)
+    # fit from a guess with narrowed bounds (src/model.py:299-304)
+    guess = model.MaternParams(n_procs=2)
+    guess.set_values(np.array([1.0, 1.0, 1.0, 1.0, 1.0, 400.0, 400.0, 400.0, 0.01, 0.01, -0.3]))
+    guess.set_bounds(nu=(0.3, 2.5), len_scale=(2e2, 1e3))
+    mod2 = model.MultivariateMatern(n_procs=2, params=guess)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod2.fit(est, guess=guess)
+    out["guess_x0"] = np.array([1.0, 1.0, 1.0, 1.0, 1.0, 400.0, 400.0, 400.0, 0.01, 0.01, -0.3])
+    out["guess_fit_x"] = mod2.params.get_values().astype(float)
+    out["guess_fit_cost"] = np.array(mod2.fit_result.cost)
+    print("fit:", out["fit_x"], out["fit_cost"], "warned", out["fit_warned"])
+    print("guess fit:", out["guess_fit_x"], out["guess_fit_cost"])
+    save("model_fit", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in list(globals().items()):

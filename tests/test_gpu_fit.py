@@ -1,0 +1,151 @@
+"""GPU parity of MultivariateMatern.fit (composite WLS, src/model.py:277-317):
+the model variograms of every cost-function call come from the device (ck_model_variogram), the
+optimiser call is the reference's (scipy L-BFGS-B, finite-difference gradient).  Checked against the
+reference's own fit results (tests/golden/model_fit.npz) and the oracle."""
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import cokrige_oracle as orc
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = ((0, 0), (0, 1), (1, 1))
+
+
+def _estimate(g):
+    from sif_xco2_cokriging_amd import fields
+    parts = []
+    for (i, j) in PAIRS:
+        n = len(g[f"centers_{i}{j}"])
+        df = pd.DataFrame({"i": i, "j": j, "bin": np.arange(n), "bin_center": g[f"centers_{i}{j}"],
+                           "bin_mean": g[f"means_{i}{j}"], "bin_count": g[f"counts_{i}{j}"]})
+        parts.append(df.set_index(["i", "j", "bin"]))
+    return fields.EmpiricalVariogram(pd.concat(parts), fields.VarioConfig(1500.0, 30), np.nan, [np.nan, np.nan])
+
+
+def _fit_groups_oracle(g):
+    return {(i, j): (g[f"centers_{i}{j}"], g[f"means_{i}{j}"], g[f"counts_{i}{j}"]) for (i, j) in PAIRS}
+
+
+def test_model_variogram_rows_vs_oracle():
+    from sif_xco2_cokriging_amd import model
+    g = load_golden("model_fit")
+    h = np.concatenate([[0.0], np.geomspace(1e-3, 3e3, 60)])
+    for x in (g["truth"], g["fit_x"], g["probes"][3]):
+        mod = model.MultivariateMatern(params=model.MaternParams().set_values(x))
+        p = orc.Params.from_flat(x)
+        for kind in ("semivariogram", "covariogram"):
+            df = mod.variograms(h, kind=kind)
+            for (i, j) in PAIRS:
+                got = df.loc[(i, j)]["variogram"].values
+                np.testing.assert_allclose(got, orc.model_variogram(p, i, j, h, kind), rtol=2e-13, atol=1e-300)
+        np.testing.assert_allclose(mod.semivariance(1, h), orc.semivariance(p, 1, h), rtol=2e-13)
+        np.testing.assert_allclose(mod.cross_semivariance(1, 0, h), orc.cross_semivariance(p, 0, 1, h), rtol=2e-13)
+
+
+def test_composite_wls_vs_reference():
+    from sif_xco2_cokriging_amd import model
+    g = load_golden("model_fit")
+    est = _estimate(g)
+    mod = model.MultivariateMatern(n_procs=2)
+    cost = np.array([mod._composite_wls(p.copy(), est.df) for p in g["probes"]])
+    # 1 - rho cancels for the nugget-free default start (cost 4e7 from the first bins): 1e-15 in K_nu -> 1e-11 here
+    np.testing.assert_allclose(cost, g["probe_cost"], rtol=1e-9)
+    # the standalone Cressie cost with the reference's fit == 0 convention (src/model.py:250-264)
+    y, f, c = np.array([1.0, 2.0, 3.0]), np.array([0.0, 1.0, 4.0]), np.array([5.0, 6.0, 7.0])
+    assert mod._weighted_least_squares(y, f, c) == pytest.approx(5.0 + 6.0 + 7.0 / 16.0)
+
+
+def _check_fit(mod, groups, ref_x, ref_cost, bounds=None):
+    """What "the same fit" can mean for L-BFGS-B on finite-difference gradients: the reference's run
+    stops on a flat valley floor and is not reproducible beyond a few percent in the parameters
+    (restarting the reference's own optimiser from its recorded answer moves on: 1618.19 -> 1608.19,
+    scripts/diag_fit.py), because 1e-15 differences in K_nu reach the gradient as 1e-3.  So:
+    (1) our cost function IS the reference's at our optimum; (2) our optimum is at least as good as
+    the recorded one; (3) the reference's optimiser (oracle), restarted at our optimum, has nowhere
+    to go; (4) the marginal parameters agree to the valley's width (the cross parameters nu_12,
+    len_12, rho_12 are weakly identified by one cross-variogram: the reference's guess run stops at
+    len_12 = 424, rho_12 = -0.10 with cost 1795.8, the converged point is len_12 = 200, rho_12 = -0.29)."""
+    x = mod.params.get_values().astype(float)
+    cost = float(mod.fit_result.cost)
+    np.testing.assert_allclose(cost, orc.composite_wls(x, groups), rtol=1e-9)
+    assert cost <= ref_cost * (1.0 + 1e-3)
+    xo, co, _ = orc.fit(groups, x0=x, bounds=bounds)
+    assert co <= cost * (1.0 + 1e-12) and co >= cost * (1.0 - 1e-4)
+    np.testing.assert_allclose(xo, x, rtol=1e-3, atol=1e-4)
+    marg = [0, 1, 2, 4, 5, 7, 8, 9]
+    np.testing.assert_allclose(x[marg], np.asarray(ref_x)[marg], rtol=0.12, atol=5e-3)
+
+
+def test_fit_vs_reference():
+    from sif_xco2_cokriging_amd import model
+    g = load_golden("model_fit")
+    est = _estimate(g)
+    groups = _fit_groups_oracle(g)
+    mod = model.MultivariateMatern(n_procs=2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert mod.fit(est) is mod
+    assert int(any("did not converge" in str(x.message) for x in w)) == int(g["fit_warned"])
+    _check_fit(mod, groups, g["fit_x"], float(g["fit_cost"]))
+    fr = mod.fit_result
+    assert fr.cs_valid is None and fr.config is est.config and fr.df_empirical is est.df
+    th = fr.df_theoretical
+    np.testing.assert_allclose(th["distance"].values, g["theo_distance"], rtol=1e-13)
+    assert np.array_equal(th.index.get_level_values("i").values, g["theo_i"])
+    assert np.array_equal(th.index.get_level_values("j").values, g["theo_j"])
+    p = orc.Params.from_flat(mod.params.get_values())
+    for (i, j) in PAIRS:
+        sel = (g["theo_i"] == i) & (g["theo_j"] == j)
+        np.testing.assert_allclose(th["variogram"].values[sel], orc.model_variogram(p, i, j, g["theo_distance"][sel]), rtol=2e-13)
+    # from a guess with narrowed bounds (src/model.py:299-304)
+    guess = model.MaternParams(n_procs=2).set_values(g["guess_x0"])
+    guess.set_bounds(nu=(0.3, 2.5), len_scale=(2e2, 1e3))
+    mod2 = model.MultivariateMatern(n_procs=2, params=guess)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod2.fit(est, guess=guess)
+    b = list(orc.PARAM_BOUNDS)
+    b[2:5] = [(0.3, 2.5)] * 3
+    b[5:8] = [(2e2, 1e3)] * 3
+    assert [tuple(t) for t in mod2.params.get_bounds()] == b
+    _check_fit(mod2, groups, g["guess_fit_x"], float(g["guess_fit_cost"]), bounds=b)
+    # process-count mismatch (src/model.py:293-296)
+    with pytest.raises(ValueError, match="Number of theoretical processes"):
+        model.MultivariateMatern(n_procs=1).fit(est)
+
+
+def test_variogram_to_fit_to_prediction_flow():
+    """K5 on the device -> fit -> joint prediction with the fitted model: the loop SURVEY section 8f-4
+    closes, end to end on the GPU, against the same flow through the oracle."""
+    from sif_xco2_cokriging_amd import fields, joint_prediction, model
+    g = load_golden("model_fit")
+    mf = fields.MultiField([fields.Field(g["coords0"], g["values0"]), fields.Field(g["coords1"], g["values1"])])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        est = mf.empirical_variograms(fields.VarioConfig(1500.0, 30))
+    for (i, j) in PAIRS:
+        df = est.df.loc[(i, j)]
+        assert np.array_equal(df["bin_count"].values, g[f"counts_{i}{j}"])
+        np.testing.assert_allclose(df["bin_mean"].values, g[f"means_{i}{j}"], rtol=1e-10, atol=1e-14)
+    mod = model.MultivariateMatern(n_procs=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod.fit(est)
+    assert float(mod.fit_result.cost) <= float(g["fit_cost"]) * (1.0 + 1e-3)
+    x = mod.params.get_values()
+    marg = [0, 1, 2, 4, 5, 7, 8, 9]
+    np.testing.assert_allclose(x[marg], g["fit_x"][marg], rtol=0.12, atol=5e-3)
+    pc = pd.DataFrame({"lat": np.linspace(30, 45, 12), "lon": np.linspace(-110, -80, 12)})
+    P = joint_prediction.Predictor(mod, mf)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pred, err = P.predict_arrays(0, pc.values)
+    rp, re = orc.joint_predict(orc.Params.from_flat(x), [g["coords0"], g["coords1"]], [g["values0"], g["values1"]],
+                               pc.values, 0, orc.METRIC_HAVERSINE)[:2]
+    np.testing.assert_allclose(pred, rp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(err, re, rtol=1e-7, atol=1e-9)

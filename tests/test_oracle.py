@@ -161,3 +161,31 @@ def test_sim_field_generator():
     n = len(g["coords"])
     np.testing.assert_allclose(z[:n], g["field0"], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(z[n:], g["field1"], rtol=1e-7, atol=1e-9)
+
+
+def _fit_groups(g):
+    return {(i, j): (g[f"centers_{i}{j}"], g[f"means_{i}{j}"], g[f"counts_{i}{j}"]) for (i, j) in ((0, 0), (0, 1), (1, 1))}
+
+
+def test_composite_wls_and_fit_vs_reference():
+    """MultivariateMatern._composite_wls at probe vectors, then fit() from the default start and from
+    a guess with narrowed bounds (src/model.py:277-317), against the reference's own results."""
+    g = load_golden("model_fit")
+    groups = _fit_groups(g)
+    cost = np.array([orc.composite_wls(p, groups) for p in g["probes"]])
+    np.testing.assert_allclose(cost, g["probe_cost"], rtol=1e-12)
+    x, c, ok = orc.fit(groups)
+    assert ok
+    np.testing.assert_allclose(c, float(g["fit_cost"]), rtol=1e-8)
+    np.testing.assert_allclose(x, g["fit_x"], rtol=1e-5, atol=1e-7)
+    b = list(orc.PARAM_BOUNDS)
+    b[2:5] = [(0.3, 2.5)] * 3
+    b[5:8] = [(2e2, 1e3)] * 3
+    x, c, ok = orc.fit(groups, x0=g["guess_x0"], bounds=b)
+    np.testing.assert_allclose(c, float(g["guess_fit_cost"]), rtol=1e-8)
+    np.testing.assert_allclose(x, g["guess_fit_x"], rtol=1e-5, atol=1e-7)
+    # the theoretical variograms FittedVariogram tabulates (src/model.py:330-331)
+    p = orc.Params.from_flat(g["fit_x"])
+    for (i, j) in ((0, 0), (0, 1), (1, 1)):
+        sel = (g["theo_i"] == i) & (g["theo_j"] == j)
+        np.testing.assert_allclose(orc.model_variogram(p, i, j, g["theo_distance"][sel]), g["theo_variogram"][sel], rtol=1e-12)
