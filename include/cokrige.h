@@ -181,6 +181,9 @@ int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,
  * `waves_per_simd` waves on every SIMD of the chip): the measured ceiling the GEMM kernels are
  * compared with, next to the datasheet 78.6 TFLOP/s. */
+/* Where the workgroups of a stream created with hipExtStreamCreateWithCUMask(cu_mask8[8]) run (NULL: an
+ * unmasked stream): out[wg] = xcc_id << 16 | se_id << 8 | sh_id << 4 | cu_id from HW_REG_XCC_ID / HW_REG_HW_ID. */
+int ck_debug_cu_probe(ck_handle* h, const uint32_t* cu_mask8, int n_wg, uint32_t* out_host);
 int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3 /* TFLOP/s, shader MHz, cycles per MFMA per wave */);
 /* Stage timings of the last calls in milliseconds (HIP events):
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,

@@ -123,6 +123,9 @@ struct ck_handle {
     // trailing update of panel K
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
+    // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
+    // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
+    int panel_group = 3;
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
@@ -672,7 +675,8 @@ extern "C" int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nby
     return 0;
 }
 
-static void gemm_timed_begin(ck_handle* h) {
+static void gemm_timed_begin(ck_handle* h, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     if (!h->time_gemm) return;
     if (h->gemm_ev_used == h->gemm_ev.size()) {
         EvPair e;
@@ -680,11 +684,12 @@ static void gemm_timed_begin(ck_handle* h) {
         (void)hipEventCreate(&e.b);
         h->gemm_ev.push_back(e);
     }
-    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].a, h->stream);
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].a, st);
 }
-static void gemm_timed_end(ck_handle* h) {
+static void gemm_timed_end(ck_handle* h, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     if (!h->time_gemm) return;
-    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].b, h->stream);
+    (void)hipEventRecord(h->gemm_ev[h->gemm_ev_used].b, st);
     h->gemm_ev_used++;
 }
 
@@ -727,9 +732,9 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     while (J0 <= Jhi && (J0 % h->world) != h->rank) ++J0;
     if (J0 > Jhi) return;
     const int nJ = (Jhi - J0) / h->world + 1;
-    if (timed) gemm_timed_begin(h);
+    if (timed) gemm_timed_begin(h, st);
     ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
-    if (timed) gemm_timed_end(h);
+    if (timed) gemm_timed_end(h, st);
 }
 
 // forward substitution of the right-hand-side rows with the diagonal block of panel K
@@ -751,11 +756,11 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     const int nJ = Jhi - Jlo + 1;
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
-    if (timed) gemm_timed_begin(h);
+    if (timed) gemm_timed_begin(h, st);
     ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
                       P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
                       h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
-    if (timed) gemm_timed_end(h);
+    if (timed) gemm_timed_end(h, st);
 }
 
 static int ensure_events(ck_handle* h) {
@@ -804,30 +809,96 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
 static int factor_sweep(ck_handle* h) {
     h->gemm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (!h->lookahead) {
+    if (h->lookahead) {
+        // Look-ahead: as soon as panel K has updated block column K + 1, the panel step of K + 1
+        // starts on the side stream and runs under the update of the columns K + 2.. by panel K.
+        if (ensure_events(h)) return -1;
+        hipStream_t M = h->stream, S = h->side;
+        panel_factor_on(h, 0, M);
+        for (int K = 0; K < h->nK; ++K) {
+            if (K > 0) HIPCHK(hipStreamWaitEvent(M, h->ev_pan[K], 0));
+            if (K + 1 < h->nK) {
+                apply_sigma_on(h, K, h->sig[K], K + 1, K + 1, M, false);
+                HIPCHK(hipEventRecord(h->ev_col[K + 1], M));
+                HIPCHK(hipStreamWaitEvent(S, h->ev_col[K + 1], 0));
+                panel_factor_on(h, K + 1, S);
+                HIPCHK(hipEventRecord(h->ev_pan[K + 1], S));
+                apply_sigma_on(h, K, h->sig[K], K + 2, h->nK - 1, M, true);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    } else if (h->panel_group <= 1) {
         for (int K = 0; K < h->nK; ++K) {
             if (ck_panel_factor(h, K)) return -1;
             if (ck_panel_apply(h, K, CK_APPLY_SIGMA)) return -1;
         }
     } else {
-        // Look-ahead: as soon as panel K has updated block column K + 1, the panel step of K + 1
-        // starts on the side stream and runs under the update of the columns K + 2.. by panel K.
-        if (ensure_events(h)) return -1;
-        panel_factor_on(h, 0, h->stream);
-        for (int K = 0; K < h->nK; ++K) {
-            if (K > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pan[K], 0));
-            if (K + 1 < h->nK) {
-                apply_sigma_on(h, K, h->sig[K], K + 1, K + 1, h->stream, false);
-                HIPCHK(hipEventRecord(h->ev_col[K + 1], h->stream));
-                HIPCHK(hipStreamWaitEvent(h->side, h->ev_col[K + 1], 0));
-                panel_factor_on(h, K + 1, h->side);
-                HIPCHK(hipEventRecord(h->ev_pan[K + 1], h->side));
-                apply_sigma_on(h, K, h->sig[K], K + 2, h->nK - 1, h->stream, true);
+        // Groups of G panels: inside a group block column K first receives the updates of the group's
+        // earlier panels in one pass (K dimension 512 g), then its panel step; the trailing matrix
+        // beyond the group is updated once with K = 512 G -- a quarter of the C traffic of G = 1.
+        const int G = h->panel_group;
+        for (int K0 = 0; K0 < h->nK; K0 += G) {
+            const int Gc = std::min(G, h->nK - K0);
+            for (int g = 0; g < Gc; ++g) {
+                if (g > 0) {
+                    gemm_timed_begin(h);
+                    ck_launch_syrk_group(h->stream, h->d_sigptr, K0, g, K0 + g, 1, h->Npad);
+                    gemm_timed_end(h);
+                }
+                panel_factor_on(h, K0 + g, h->stream);
+            }
+            if (K0 + Gc < h->nK) {
+                gemm_timed_begin(h);
+                ck_launch_syrk_group(h->stream, h->d_sigptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->Npad);
+                gemm_timed_end(h);
             }
         }
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
+    return 0;
+}
+
+// forward sweep of the right-hand-side rows through the factor (the L panels are final)
+static int solve_sweep(ck_handle* h) {
+    if (h->lookahead) {
+        if (ensure_events(h)) return -1;
+        hipStream_t M = h->stream, S = h->side;
+        aux_inner_on(h, 0, h->sig[0], M);
+        for (int K = 0; K < h->nK; ++K) {
+            if (K > 0) HIPCHK(hipStreamWaitEvent(M, h->ev_pan[K], 0));
+            if (K + 1 < h->nK) {
+                aux_update_on(h, K, h->sig[K], K + 1, K + 1, M, false);
+                HIPCHK(hipEventRecord(h->ev_col[K + 1], M));
+                HIPCHK(hipStreamWaitEvent(S, h->ev_col[K + 1], 0));
+                aux_inner_on(h, K + 1, h->sig[K + 1], S);
+                HIPCHK(hipEventRecord(h->ev_pan[K + 1], S));
+                aux_update_on(h, K, h->sig[K], K + 2, h->nK - 1, M, true);
+            }
+        }
+    } else if (h->panel_group <= 1) {
+        for (int K = 0; K < h->nK; ++K)
+            if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    } else {
+        const int G = h->panel_group;
+        for (int K0 = 0; K0 < h->nK; K0 += G) {
+            const int Gc = std::min(G, h->nK - K0);
+            for (int g = 0; g < Gc; ++g) {
+                if (g > 0) {
+                    gemm_timed_begin(h);
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_sigptr, K0, g, K0 + g, 1);
+                    gemm_timed_end(h);
+                }
+                aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
+            }
+            if (K0 + Gc < h->nK) {
+                gemm_timed_begin(h);
+                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_sigptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc);
+                gemm_timed_end(h);
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -972,25 +1043,7 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, h->stream));
-    if (!h->lookahead) {
-        for (int K = 0; K < h->nK; ++K)
-            if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
-    } else {
-        if (ensure_events(h)) return -1;
-        aux_inner_on(h, 0, h->sig[0], h->stream);
-        for (int K = 0; K < h->nK; ++K) {
-            if (K > 0) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pan[K], 0));
-            if (K + 1 < h->nK) {
-                aux_update_on(h, K, h->sig[K], K + 1, K + 1, h->stream, false);
-                HIPCHK(hipEventRecord(h->ev_col[K + 1], h->stream));
-                HIPCHK(hipStreamWaitEvent(h->side, h->ev_col[K + 1], 0));
-                aux_inner_on(h, K + 1, h->sig[K + 1], h->side);
-                HIPCHK(hipEventRecord(h->ev_pan[K + 1], h->side));
-                aux_update_on(h, K, h->sig[K], K + 2, h->nK - 1, h->stream, true);
-            }
-        }
-        HIPCHK(hipGetLastError());
-    }
+    if (solve_sweep(h)) return -1;
     HIPCHK(hipEventRecord(e1, h->stream));
     if (ck_aux_finish(h, pred, pred_err)) return -1;
     float ms = 0;
@@ -1055,8 +1108,7 @@ extern "C" int ck_loocv(ck_handle* h, int i, double* pred, double* pred_err) {
     HIPCHK(hipMemsetAsync(h->aux, 0, (size_t)h->mpad * h->Npad * 8, h->stream));
     ck_launch_loo_rows(h->stream, h->aux, h->mpad, m, i == 0 ? 0 : h->n0p, h->z, h->Npad);
     HIPCHK(hipGetLastError());
-    for (int K = 0; K < h->nK; ++K)
-        if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
+    if (solve_sweep(h)) return -1;
     ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, m, m, -1.0, h->d_pred, h->d_err);
     HIPCHK(hipGetLastError());
     std::vector<double> s1(m), s2(m);
@@ -1385,6 +1437,26 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     return 0;
 }
 
+extern "C" int ck_debug_cu_probe(ck_handle* h, const uint32_t* cu_mask8, int n_wg, uint32_t* out) {
+    CHKH(h);
+    if (n_wg <= 0 || n_wg > 65536 || !out) return fail("bad n_wg");
+    hipStream_t st = nullptr;
+    if (cu_mask8)
+        HIPCHK(hipExtStreamCreateWithCUMask(&st, 8, cu_mask8));
+    else
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    unsigned* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n_wg * 4));
+    HIPCHK(hipMemsetAsync(d, 0xff, (size_t)n_wg * 4, st));
+    ck_launch_cu_probe(st, d, n_wg, 4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, (size_t)n_wg * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return 0;
+}
+
 extern "C" int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3) {
     CHKH(h);
     if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) return fail("bad arguments");
@@ -1425,6 +1497,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
         h->lookahead = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "panel_group")) {   // panels per trailing update (1 = after every panel)
+        if (value < 1 || value > 16) return fail("panel_group must be in [1, 16]");
+        h->panel_group = (int)value;
         return 0;
     }
     if (!strcmp(name, "site_order")) {   // 0: caller's order | 1: Hilbert order (see ck_handle::site_order)

@@ -740,6 +740,203 @@ __global__ __launch_bounds__(512, 4) void k_syrk_panels_e(double* const* __restr
     gemm_tile_e<0>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
+// ---------------------------------------------------------------------------------------
+// Multi-panel K: C -= sum_p A_p B_p^T in ONE pass over the C tile (option "panel_group")
+// ---------------------------------------------------------------------------------------
+// With K = 512 per trailing update, the 128 x 128 tile spends ~7 % of its time loading and
+// storing C (accumulators = C tile; measured 61.7 TF at K = 512 against 65.5 at K = 2048 and 66.2
+// at K = 8192).  The factorisation therefore groups G panels (ck_api.hip: factor_sweep): the
+// trailing matrix beyond a group is updated once with K = 512 G, its A / B operands coming from G
+// different panel buffers.  Same tile, LDS image and chunk pipeline as gemm_tile_s / gemm_tile_e;
+// the source pointers change every 32 chunks (wave-uniform, scalar loads).
+//   WAVES = 4: 64 x 64 per wave, two workgroups per CU = 2 waves per SIMD (256 VGPRs)
+//   WAVES = 8: 64 x 32 per wave, two workgroups per CU = 4 waves per SIMD (128 VGPRs)
+// SRC::get(p, A, B): byte pointers to row r0 of A_p and row c0 of B_p (both ld = CK_NB doubles).
+template <int WAVES, class SRC>
+__device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
+                                            char* lds) {
+    constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
+    constexpr int STAGE = 256 * 128;
+    constexpr int WJ = WAVES == 4 ? 4 : 2;       // 16-column MFMA tiles per wave
+    constexpr int NU = WAVES == 4 ? 4 : 2;       // staged 16-byte pieces per thread and operand
+    constexpr int RSTEP = WAVES * 8;             // rows between a thread's pieces (threads / 8)
+    constexpr int NST = CK_NB / GEMM_BK;         // chunks per panel
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wm = WAVES == 4 ? (w >> 1) : (w >> 2), wn = WAVES == 4 ? (w & 1) : (w & 3);
+    const int li = lane & 15, g = lane >> 4;
+
+    double* Cb = C + r0 * ldc + c0;
+    const int srow = tid >> 3, sp = tid & 7;
+    const unsigned src0 = (unsigned)(srow * CK_NB + sp * 2) * 8u;
+    const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
+    constexpr long u_step = (long)RSTEP * CK_NB * 8;   // bytes
+    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * (WJ * 16) + li) * 8u;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int slot = (4 * kb + g) ^ (li >> 1);
+        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
+        b_rd[kb] = BOFF + (wn * (WJ * 16) + li) * 128 + slot * 16;
+    }
+
+    const char *Ab, *Bb;
+    src.get(0, Ab, Bb);
+    d2_t ra[NU], rb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        ra[u] = *reinterpret_cast<const d2_t*>(Ab + u * u_step + src0);
+        rb[u] = *reinterpret_cast<const d2_t*>(Bb + u * u_step + src0);
+    }
+    d4_t acc[4][WJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
+        }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        *reinterpret_cast<d2_t*>(lds + s_dst0 + u * (RSTEP * 128)) = -ra[u];
+        *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
+    __syncthreads();
+
+    const int nst = np * NST;
+    int pnl = 0, kc = 0;             // panel and chunk-in-panel of the chunk being PREFETCHED
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1 < nst);
+        if (more) {
+            if (++kc == NST) {
+                kc = 0;
+                src.get(++pnl, Ab, Bb);
+            }
+            const long k0 = (long)kc * (GEMM_BK * 8);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                ra[u] = *reinterpret_cast<const d2_t*>(Ab + (k0 + u * u_step) + src0);
+                rb[u] = *reinterpret_cast<const d2_t*>(Bb + (k0 + u * u_step) + src0);
+            }
+        }
+        const char* sb = lds + cur * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            d2_t af[4], bf[WJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* nx = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                *reinterpret_cast<d2_t*>(nx + s_dst0 + u * (RSTEP * 128)) = -ra[u];
+                *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
+        }
+}
+
+// operands of the grouped Cholesky trailing update: panels K0 .. K0 + np - 1, block column J
+struct CkSrcSyrk {
+    double* const* sigptr;
+    int K0, J;
+    long r0, c0;
+    __device__ __forceinline__ void get(int p, const char*& A, const char*& B) const {
+        const double* base = sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB;
+        A = reinterpret_cast<const char*>(base + r0 * CK_NB);
+        B = reinterpret_cast<const char*>(base + c0 * CK_NB);
+    }
+};
+
+// operands of the grouped right-hand-side update: aux block columns K0.., L panels K0.., target column J
+struct CkSrcAux {
+    const double* aux;
+    long mpad;
+    double* const* sigptr;
+    int K0, J;
+    long r0, c0;
+    __device__ __forceinline__ void get(int p, const char*& A, const char*& B) const {
+        A = reinterpret_cast<const char*>(aux + (long)(K0 + p) * mpad * CK_NB + r0 * CK_NB);
+        B = reinterpret_cast<const char*>(sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB + c0 * CK_NB);
+    }
+};
+
+// block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 4) void k_syrk_group(double* const* __restrict__ sigptr,
+                                                                               int K0, int np, int J0, long Npad) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = J0 + (int)blockIdx.y;
+    const long M = Npad - (long)J * CK_NB;
+    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if (r0 + 127 < c0) return;
+    const CkSrcSyrk src{sigptr, K0, J, r0, c0};
+    gemm_tile_m<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
+}
+
+// aux block columns J = J0 + blockIdx.y -= sum over p of aux[K0 + p] L[J, K0 + p]^T
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 4) void k_aux_group(double* __restrict__ aux, long mpad,
+                                                                              double* const* __restrict__ sigptr,
+                                                                              int K0, int np, int J0) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = J0 + (int)blockIdx.y;
+    const int tiles_n = CK_NB / 128;
+    const int nblk = (int)(mpad / 128) * tiles_n;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
+    gemm_tile_m<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
+}
+
+void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int np, int J0, int nJ, int64_t Npad) {
+    if (nJ <= 0 || np <= 0) return;
+    const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
+    const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
+    if (g_ck_gemm_variant == 5)
+        k_syrk_group<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+    else
+        k_syrk_group<4><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+}
+
+void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
+                         int nJ) {
+    if (nJ <= 0 || np <= 0 || mpad <= 0) return;
+    const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
+    if (g_ck_gemm_variant == 5)
+        k_aux_group<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+    else
+        k_aux_group<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+}
+
 // plain (optionally batched over blockIdx.y) form
 template <int WN, int VAR>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long ldc, const double* __restrict__ A,
@@ -788,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restric
         gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
-int g_ck_gemm_variant = 4;   // 4: 128x128 tiles, two workgroups per CU (default); 0: 256x128 plane/XOR image; 1: padded rows + b64 reads; 2: ping-pong + LDS-DMA
+int g_ck_gemm_variant = 5;   // 5: 128x128 tiles, 8 waves of 64x32, two workgroups per CU (default); 4: the same with 4 waves of 64x64; 0: 256x128 plane/XOR image; 1: padded rows + b64 reads; 2: ping-pong + LDS-DMA
 
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
@@ -1154,3 +1351,20 @@ int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters
     k_mfma_peak<16, 1><<<dim3(blocks), dim3(256), 0, s>>>(iters, sink);
     return 16;
 }
+
+// ---------------------------------------------------------------------------------------
+// where do the workgroups of a CU-masked stream run?  (ck_debug_cu_probe)
+// ---------------------------------------------------------------------------------------
+__global__ void k_cu_probe(unsigned* out, int spin) {
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID, 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID[3:0]
+        out[blockIdx.x] = (xcc << 16) | (((hw >> 13) & 7u) << 8) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+    }
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);   // keep the slot busy so that the grid spreads out
+}
+
+void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin) {
+    k_cu_probe<<<dim3((unsigned)n_wg), dim3(64), 0, s>>>(out, spin);
+}
+

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import numpy as np
 
@@ -63,6 +63,7 @@ _PROTOS = {
     "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
+    "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
     "ck_timings": [c_void_p, _dp, c_int],
     "ck_table_fallbacks": [c_void_p, c_int, POINTER(c_int64)],
@@ -361,6 +362,17 @@ class Handle:
         c = c_int64(0)
         _chk(lib().ck_table_fallbacks(self._h, int(bool(reset)), byref(c)))
         return c.value
+
+    def cu_probe(self, mask_words=None, n_wg=4096):
+        """(xcc, se, sh, cu) of each workgroup of a launch on a CU-masked stream (None: unmasked)."""
+        out = np.zeros(int(n_wg), dtype=np.uint32)
+        mp = None
+        if mask_words is not None:
+            mk = np.ascontiguousarray(mask_words, dtype=np.uint32)
+            assert mk.size == 8
+            mp = mk.ctypes.data_as(POINTER(c_uint32))
+        _chk(lib().ck_debug_cu_probe(self._h, mp, int(n_wg), out.ctypes.data_as(POINTER(c_uint32))))
+        return np.stack([out >> 16, (out >> 8) & 7, (out >> 4) & 1, out & 15], axis=1)
 
     def mfma_peak(self, waves_per_simd=1, iters=20000):
         out = np.zeros(3)

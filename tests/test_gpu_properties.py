@@ -8,9 +8,11 @@ from oracle import cokrige_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _handle(pb, values=None, order=None):
+def _handle(pb, values=None, order=None, options=None):
     from sif_xco2_cokriging_amd import native
     h = native.Handle(0)
+    for name, value in (options or {}).items():
+        h.set_option(name, value)
     pv = pb["params"]
     h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
     h.set_metric(pb["metric"])
@@ -42,6 +44,30 @@ def test_against_oracle_n1500(shape):
         rp, re = orc.joint_predict(p, pb["coords"], pb["values"], pc, i, pb["metric"])
         assert rel(pred, rp) < 1e-8, shape
         assert np.max(np.abs(err ** 2 - re ** 2)) < 1e-9
+
+
+@pytest.mark.parametrize("group,variant", [(1, 4), (3, 4), (4, 5), (16, 5)])
+def test_panel_groups_and_tile_variants(group, variant):
+    """The grouped factorisation / solve (trailing updates with K = 512 G from G panel buffers, option
+    panel_group) for group sizes that do and do not divide the 7 panels, on both multi-panel tile
+    forms (gemm_variant 4: 4 waves, 5: 8 waves) -- predictions and LOOCV against the oracle."""
+    from sif_xco2_cokriging_amd import synth
+    pb = synth.conus_problem(1700, seed=11)
+    pc = pb["pcoords"][::11][:700]
+    h = _handle(pb, options={"panel_group": group, "gemm_variant": variant})
+    try:
+        p = orc.Params.from_flat(pb["params"])
+        pred, err = h.predict(1, pc)
+        rp, re = orc.joint_predict(p, pb["coords"], pb["values"], pc, 1, pb["metric"])
+        assert rel(pred, rp) < 1e-8
+        assert np.max(np.abs(err ** 2 - re ** 2)) < 1e-9
+        cp, ce = h.loocv(0, 1700)
+        for ix in (0, 611, 1699):   # the reference's leave-one-out loop, three of its 1 700 solves
+            op, oe = orc.joint_predict(p, pb["coords"], pb["values"], pb["coords"][0][ix], 0, pb["metric"], cv_ix=ix)
+            assert abs(cp[ix] - op[0]) < 1e-8 * max(1.0, abs(op[0])) and abs(ce[ix] ** 2 - oe[0] ** 2) < 1e-9
+    finally:
+        h.set_option("gemm_variant", 5)   # process-wide switch, back to the default
+        h.close()
 
 
 def test_config2_properties_n5000():
