@@ -135,6 +135,10 @@ int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nbytes);
 /* Apply panel K to the local trailing block columns (CK_APPLY_SIGMA) and/or to the
  * right-hand-side rows (CK_APPLY_AUX). */
 int ck_panel_apply(ck_handle* h, int K, int what);
+/* The CK_APPLY_SIGMA part restricted to the locally owned block columns J in [J_lo, J_hi] (clipped to
+ * K + 1 .. n_panels - 1).  With it the host can run the classical look-ahead: update column K + 1 first,
+ * factor it, start its broadcast, and update the remaining columns under the broadcast. */
+int ck_panel_apply_sigma(ck_handle* h, int K, int J_lo, int J_hi);
 /* pred / pred_err of the local shard after all panels were applied to the aux rows. */
 int ck_aux_finish(ck_handle* h, double* pred_host, double* pred_err_host);
 /* info flag of the factorisation so far (synchronises). */

@@ -797,6 +797,17 @@ extern "C" int ck_panel_apply(ck_handle* h, int K, int what) {
     return 0;
 }
 
+extern "C" int ck_panel_apply_sigma(ck_handle* h, int K, int J_lo, int J_hi) {
+    CHKH(h);
+    if (K < 0 || K >= h->nK) return fail("bad panel index");
+    J_lo = std::max(J_lo, K + 1);
+    J_hi = std::min(J_hi, h->nK - 1);
+    if (J_lo > J_hi) return 0;
+    apply_sigma_on(h, K, panel_src(h, K), J_lo, J_hi, h->stream, true);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     CHKH(h);
     long long v = 0;

@@ -42,6 +42,16 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // (acc = C + (-A) B^T), so the epilogue is stores only.
 #define GEMM_BK 16
 
+// A pointer LOADED from memory (sigptr[J]) is a generic pointer to hipcc: accesses through it become
+// flat_load / flat_store, and a flat access counts on lgkmcnt as well as vmcnt -- every
+// s_waitcnt lgkmcnt(0) in front of the MFMAs (meant for the ds_reads) would then also wait for the
+// global prefetch of the next chunk.  as_global() puts such pointers back into the global address space.
+typedef __attribute__((address_space(1))) char ck_gchar;
+typedef __attribute__((address_space(1))) double ck_gdouble;
+typedef __attribute__((address_space(1))) d2_t ck_gd2;
+__device__ __forceinline__ const ck_gchar* as_global(const char* p) { return (const ck_gchar*)(unsigned long long)p; }
+__device__ __forceinline__ ck_gchar* as_global(char* p) { return (ck_gchar*)(unsigned long long)p; }
+
 template <int WN>
 __device__ __forceinline__ void gemm_tile(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
                                           const double* __restrict__ B, long ldb, long r0, long c0, int K,
@@ -481,9 +491,9 @@ __device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, co
     const int wm = w >> 1, wn = w & 1;
     const int li = lane & 15, g = lane >> 4;
 
-    const char* Ab = reinterpret_cast<const char*>(A + r0 * lda);
-    const char* Bb = reinterpret_cast<const char*>(B + c0 * ldb);
-    double* Cb = C + r0 * ldc + c0;
+    const ck_gchar* Ab = as_global(reinterpret_cast<const char*>(A + r0 * lda));
+    const ck_gchar* Bb = as_global(reinterpret_cast<const char*>(B + c0 * ldb));
+    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
     // staging: chunk (row = tid >> 3 (+32 u), pair p = tid & 7) -> slot p ^ ((row >> 1) & 7); row + 32 u keeps the swizzle
     const int srow = tid >> 3, sp = tid & 7;
     const unsigned a_src0 = (unsigned)(srow * (int)lda + sp * 2) * 8u;
@@ -502,17 +512,17 @@ __device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, co
     d2_t ra[4], rb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        ra[u] = *reinterpret_cast<const d2_t*>(Ab + u * a_step + a_src0);
-        rb[u] = *reinterpret_cast<const d2_t*>(Bb + u * b_step + b_src0);
+        ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * a_step + a_src0);
+        rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * b_step + b_src0);
     }
     d4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
+            for (int j = 0; j < 4; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
         }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -533,8 +543,8 @@ __device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, co
             const long k0 = (long)(st + 1) * (GEMM_BK * 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ra[u] = *reinterpret_cast<const d2_t*>(Ab + (k0 + u * a_step) + a_src0);
-                rb[u] = *reinterpret_cast<const d2_t*>(Bb + (k0 + u * b_step) + b_src0);
+                ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * a_step) + a_src0);
+                rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * b_step) + b_src0);
             }
         }
         const char* sb = lds + cur * STAGE;
@@ -567,9 +577,9 @@ __device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, co
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
         }
 }
 
@@ -621,9 +631,9 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
     const int wm = w >> 2, wn = w & 3;
     const int li = lane & 15, g = lane >> 4;
 
-    const char* Ab = reinterpret_cast<const char*>(A + r0 * lda);
-    const char* Bb = reinterpret_cast<const char*>(B + c0 * ldb);
-    double* Cb = C + r0 * ldc + c0;
+    const ck_gchar* Ab = as_global(reinterpret_cast<const char*>(A + r0 * lda));
+    const ck_gchar* Bb = as_global(reinterpret_cast<const char*>(B + c0 * ldb));
+    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
     // staging: chunk (row = tid >> 3 (+64 u), pair p = tid & 7) -> slot p ^ ((row >> 1) & 7); row + 64 u keeps the swizzle
     const int srow = tid >> 3, sp = tid & 7;
     const unsigned a_src0 = (unsigned)(srow * (int)lda + sp * 2) * 8u;
@@ -642,17 +652,17 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
     d2_t ra[2], rb[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        ra[u] = *reinterpret_cast<const d2_t*>(Ab + u * a_step + a_src0);
-        rb[u] = *reinterpret_cast<const d2_t*>(Bb + u * b_step + b_src0);
+        ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * a_step + a_src0);
+        rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * b_step + b_src0);
     }
     d4_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
+            for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
         }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -670,8 +680,8 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
             const long k0 = (long)(st + 1) * (GEMM_BK * 8);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                ra[u] = *reinterpret_cast<const d2_t*>(Ab + (k0 + u * a_step) + a_src0);
-                rb[u] = *reinterpret_cast<const d2_t*>(Bb + (k0 + u * b_step) + b_src0);
+                ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * a_step) + a_src0);
+                rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * b_step) + b_src0);
             }
         }
         const char* sb = lds + cur * STAGE;
@@ -704,9 +714,9 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
         }
 }
 
@@ -749,24 +759,30 @@ __global__ __launch_bounds__(512, 4) void k_syrk_panels_e(double* const* __restr
 // trailing matrix beyond a group is updated once with K = 512 G, its A / B operands coming from G
 // different panel buffers.  Same tile, LDS image and chunk pipeline as gemm_tile_s / gemm_tile_e;
 // the source pointers change every 32 chunks (wave-uniform, scalar loads).
-//   WAVES = 4: 64 x 64 per wave, two workgroups per CU = 2 waves per SIMD (256 VGPRs)
-//   WAVES = 8: 64 x 32 per wave, two workgroups per CU = 4 waves per SIMD (128 VGPRs)
+//   WAVES = 4, TN = 128: 64 x 64 per wave, two workgroups per CU = 2 waves per SIMD (256 VGPRs)
+//   WAVES = 8, TN = 128: 64 x 32 per wave, two workgroups per CU = 4 waves per SIMD (128 VGPRs)
+//   WAVES = 4, TN = 64:  128 x 64 tile, 64 x 32 per wave, 48 KB of LDS: THREE workgroups per CU, i.e.
+//                        three waves per SIMD that belong to different workgroups and never wait
+//                        at the same barrier (with 8 waves per workgroup two of a SIMD's four do)
 // SRC::get(p, A, B): byte pointers to row r0 of A_p and row c0 of B_p (both ld = CK_NB doubles).
-template <int WAVES, class SRC>
+template <int WAVES, int TN, class SRC>
 __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
                                             char* lds) {
+    static_assert((WAVES == 4 && (TN == 128 || TN == 64)) || (WAVES == 8 && TN == 128), "tile shapes");
     constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
-    constexpr int STAGE = 256 * 128;
-    constexpr int WJ = WAVES == 4 ? 4 : 2;       // 16-column MFMA tiles per wave
-    constexpr int NU = WAVES == 4 ? 4 : 2;       // staged 16-byte pieces per thread and operand
+    constexpr int STAGE = (128 + TN) * 128;
+    constexpr int WCOLS = WAVES == 8 ? 4 : 2;    // waves across the tile's columns
+    constexpr int WJ = TN / WCOLS / 16;          // 16-column MFMA tiles per wave
     constexpr int RSTEP = WAVES * 8;             // rows between a thread's pieces (threads / 8)
+    constexpr int NUA = 128 / RSTEP;             // staged 16-byte pieces per thread: A rows
+    constexpr int NUB = TN / RSTEP;              // ... B rows
     constexpr int NST = CK_NB / GEMM_BK;         // chunks per panel
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int wm = WAVES == 4 ? (w >> 1) : (w >> 2), wn = WAVES == 4 ? (w & 1) : (w & 3);
+    const int wm = w / WCOLS, wn = w % WCOLS;
     const int li = lane & 15, g = lane >> 4;
 
-    double* Cb = C + r0 * ldc + c0;
+    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
     const int srow = tid >> 3, sp = tid & 7;
     const unsigned src0 = (unsigned)(srow * CK_NB + sp * 2) * 8u;
     const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
@@ -780,28 +796,26 @@ __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, co
         b_rd[kb] = BOFF + (wn * (WJ * 16) + li) * 128 + slot * 16;
     }
 
-    const char *Ab, *Bb;
+    const ck_gchar *Ab, *Bb;
     src.get(0, Ab, Bb);
-    d2_t ra[NU], rb[NU];
+    d2_t ra[NUA], rb[NUB];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        ra[u] = *reinterpret_cast<const d2_t*>(Ab + u * u_step + src0);
-        rb[u] = *reinterpret_cast<const d2_t*>(Bb + u * u_step + src0);
-    }
+    for (int u = 0; u < NUA; ++u) ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * u_step + src0);
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * u_step + src0);
     d4_t acc[4][WJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < WJ; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
+            for (int j = 0; j < WJ; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
         }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        *reinterpret_cast<d2_t*>(lds + s_dst0 + u * (RSTEP * 128)) = -ra[u];
-        *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
-    }
+    for (int u = 0; u < NUA; ++u) *reinterpret_cast<d2_t*>(lds + s_dst0 + u * (RSTEP * 128)) = -ra[u];
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
     __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
     __syncthreads();
 
@@ -817,10 +831,9 @@ __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, co
             }
             const long k0 = (long)kc * (GEMM_BK * 8);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                ra[u] = *reinterpret_cast<const d2_t*>(Ab + (k0 + u * u_step) + src0);
-                rb[u] = *reinterpret_cast<const d2_t*>(Bb + (k0 + u * u_step) + src0);
-            }
+            for (int u = 0; u < NUA; ++u) ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * u_step) + src0);
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * u_step) + src0);
         }
         const char* sb = lds + cur * STAGE;
 #pragma unroll
@@ -841,10 +854,9 @@ __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, co
         if (more) {
             char* nx = lds + (cur ^ 1) * STAGE;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                *reinterpret_cast<d2_t*>(nx + s_dst0 + u * (RSTEP * 128)) = -ra[u];
-                *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
-            }
+            for (int u = 0; u < NUA; ++u) *reinterpret_cast<d2_t*>(nx + s_dst0 + u * (RSTEP * 128)) = -ra[u];
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
         }
         __syncthreads();
     }
@@ -852,9 +864,9 @@ __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, co
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
-            for (int j = 0; j < WJ; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
+            for (int j = 0; j < WJ; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
         }
 }
 
@@ -863,10 +875,10 @@ struct CkSrcSyrk {
     double* const* sigptr;
     int K0, J;
     long r0, c0;
-    __device__ __forceinline__ void get(int p, const char*& A, const char*& B) const {
+    __device__ __forceinline__ void get(int p, const ck_gchar*& A, const ck_gchar*& B) const {
         const double* base = sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB;
-        A = reinterpret_cast<const char*>(base + r0 * CK_NB);
-        B = reinterpret_cast<const char*>(base + c0 * CK_NB);
+        A = as_global(reinterpret_cast<const char*>(base + r0 * CK_NB));
+        B = as_global(reinterpret_cast<const char*>(base + c0 * CK_NB));
     }
 };
 
@@ -877,64 +889,73 @@ struct CkSrcAux {
     double* const* sigptr;
     int K0, J;
     long r0, c0;
-    __device__ __forceinline__ void get(int p, const char*& A, const char*& B) const {
-        A = reinterpret_cast<const char*>(aux + (long)(K0 + p) * mpad * CK_NB + r0 * CK_NB);
-        B = reinterpret_cast<const char*>(sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB + c0 * CK_NB);
+    __device__ __forceinline__ void get(int p, const ck_gchar*& A, const ck_gchar*& B) const {
+        A = as_global(reinterpret_cast<const char*>(aux + (long)(K0 + p) * mpad * CK_NB + r0 * CK_NB));
+        B = as_global(reinterpret_cast<const char*>(sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB + c0 * CK_NB));
     }
 };
 
 // block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 4) void k_syrk_group(double* const* __restrict__ sigptr,
-                                                                               int K0, int np, int J0, long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+template <int WAVES, int TN>
+__global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_syrk_group(
+    double* const* __restrict__ sigptr, int K0, int np, int J0, long Npad) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * (128 + TN) * 128];
     const int J = J0 + (int)blockIdx.y;
     const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
+    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / TN;
     const int nblk = tiles_m * tiles_n;
     if ((int)blockIdx.x >= nblk) return;
     const int t = xcd_remap(blockIdx.x, nblk);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    const long r0 = (long)tm * 128, c0 = (long)tn * TN;
     if (r0 + 127 < c0) return;
     const CkSrcSyrk src{sigptr, K0, J, r0, c0};
-    gemm_tile_m<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
+    gemm_tile_m<WAVES, TN>(sigptr[J], CK_NB, src, np, r0, c0, lds);
 }
 
 // aux block columns J = J0 + blockIdx.y -= sum over p of aux[K0 + p] L[J, K0 + p]^T
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 4) void k_aux_group(double* __restrict__ aux, long mpad,
-                                                                              double* const* __restrict__ sigptr,
-                                                                              int K0, int np, int J0) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+template <int WAVES, int TN>
+__global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_aux_group(
+    double* __restrict__ aux, long mpad, double* const* __restrict__ sigptr, int K0, int np, int J0) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * (128 + TN) * 128];
     const int J = J0 + (int)blockIdx.y;
-    const int tiles_n = CK_NB / 128;
+    const int tiles_n = CK_NB / TN;
     const int nblk = (int)(mpad / 128) * tiles_n;
     const int t = xcd_remap(blockIdx.x, nblk);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    const long r0 = (long)tm * 128, c0 = (long)tn * TN;
     const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
-    gemm_tile_m<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
+    gemm_tile_m<WAVES, TN>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
 
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int np, int J0, int nJ, int64_t Npad) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
+    if (g_ck_gemm_variant == 6) {
+        const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 64)), (unsigned)nJ);
+        k_syrk_group<4, 64><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+        return;
+    }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (g_ck_gemm_variant == 5)
-        k_syrk_group<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+    if (g_ck_gemm_variant == 4)
+        k_syrk_group<4, 128><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
     else
-        k_syrk_group<4><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+        k_syrk_group<8, 128><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
 }
 
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ) {
     if (nJ <= 0 || np <= 0 || mpad <= 0) return;
+    if (g_ck_gemm_variant == 6) {
+        const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 64)), (unsigned)nJ);
+        k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        return;
+    }
     const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (g_ck_gemm_variant == 5)
-        k_aux_group<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+    if (g_ck_gemm_variant == 4)
+        k_aux_group<4, 128><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
     else
-        k_aux_group<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        k_aux_group<8, 128><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
 }
 
 // plain (optionally batched over blockIdx.y) form
@@ -992,7 +1013,7 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
                        int64_t sC, int64_t sA, int64_t sB) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
     const int v = g_ck_gemm_variant;
-    if (v == 5 && N % 128 == 0) {
+    if ((v == 5 || v == 6) && N % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
                                                              sC, sA, sB);
@@ -1043,7 +1064,7 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
     if (nJ <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
-    if (g_ck_gemm_variant == 5) {
+    if (g_ck_gemm_variant == 5 || g_ck_gemm_variant == 6) {
         k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
         return;

@@ -8,9 +8,12 @@ Partition (include/cokrige.h, "step-wise form"):
   * prediction points: contiguous shards, one per rank -- each rank assembles its own rows of
     c0^T and forward-substitutes them with every panel it sees, so the solve rides on the
     panel broadcasts and needs no collective of its own;
-  * per Cholesky step K: the owner factors panel K, broadcasts the packed panel
-    ((Npad - K NB) x NB doubles, contiguous), every rank updates its own trailing block columns
-    and its own right-hand-side rows;
+  * per Cholesky step K: every rank holds panel K (the owner's storage or a receive buffer); the
+    owner of K + 1 updates block column K + 1 first, factors it and the broadcast of panel K + 1
+    ((Npad - (K + 1) NB) x NB doubles, contiguous) starts at once -- asynchronously, into the
+    other of the two receive buffers -- while every rank updates the rest of its trailing block
+    columns and its right-hand-side rows with panel K (look-ahead of depth 1: the panel step and
+    the transfer run under the update instead of in front of it);
   * at the end: all-gather of the 2 m result values, MIN-reduce of the LAPACK-style info flag.
 
 The torch tensors are plumbing: device memory (one uint8 arena the library carves its panels
@@ -26,9 +29,10 @@ _BIG = np.iinfo(np.int64).max
 
 
 class DistributedJoint:
-    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None):
+    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
+        self.lookahead = bool(lookahead)
         self.arena = None
         self.timings = {}
 
@@ -64,6 +68,28 @@ class DistributedJoint:
         assert 0 <= off and off + nbytes <= self.arena.numel(), "panel outside the arena"
         return self.arena[off:off + nbytes].view(torch.float64)
 
+    def _sweep_lookahead(self, nK):
+        """Factor / broadcast / apply with the next panel's factorisation and transfer under the
+        current panel's update.  The collective is enqueued BEFORE the big update kernels, so its
+        kernel holds its few CUs before they fill the chip; it reads panel K + 1 and writes the
+        receive buffer (K + 1) & 1, the update reads panel K (buffer K & 1) and writes columns
+        beyond K + 1 -- disjoint."""
+        h, dist = self.h, self.dist
+        if self.rank == 0:
+            h.panel_factor(0)
+        dist.broadcast(self._panel_tensor(0), src=0, group=self.group)
+        for K in range(nK):
+            nxt, work = K + 1, None
+            if nxt < nK:
+                if nxt % self.world == self.rank:
+                    h.panel_apply_sigma(K, nxt, nxt)
+                    h.panel_factor(nxt)
+                work = dist.broadcast(self._panel_tensor(nxt), src=nxt % self.world, group=self.group, async_op=True)
+            h.panel_apply_sigma(K, nxt + 1, nK - 1)
+            h.panel_apply(K, native.APPLY_AUX)
+            if work is not None:
+                work.wait()
+
     # -- one pass of the hot path ---------------------------------------------------------------------
     def predict(self, i: int, pcoords):
         """assemble -> (factor + broadcast + apply) per panel -> reduce; returns the full-length
@@ -77,13 +103,16 @@ class DistributedJoint:
         h.assemble_joint()
         h.aux_begin(i, pc[lo:hi])
         nK, _, _ = h.num_panels()
-        for K in range(nK):
-            owner = K % self.world
-            if owner == self.rank:
-                h.panel_factor(K)
-            if self.world > 1:
-                dist.broadcast(self._panel_tensor(K), src=owner, group=self.group)
-            h.panel_apply(K, native.APPLY_SIGMA | native.APPLY_AUX)
+        if self.world > 1 and self.lookahead:
+            self._sweep_lookahead(nK)
+        else:
+            for K in range(nK):
+                owner = K % self.world
+                if owner == self.rank:
+                    h.panel_factor(K)
+                if self.world > 1:
+                    dist.broadcast(self._panel_tensor(K), src=owner, group=self.group)
+                h.panel_apply(K, native.APPLY_SIGMA | native.APPLY_AUX)
         pred_l, err_l = h.aux_finish()
         info = h.factor_info()
         if self.world == 1:

@@ -51,6 +51,7 @@ _PROTOS = {
     "ck_panel_factor": [c_void_p, c_int],
     "ck_panel_buffer": [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)],
     "ck_panel_apply": [c_void_p, c_int, c_int],
+    "ck_panel_apply_sigma": [c_void_p, c_int, c_int, c_int],
     "ck_aux_finish": [c_void_p, _dp, _dp],
     "ck_factor_info": [c_void_p, POINTER(c_int64)],
     "ck_predict_local": [c_void_p, c_int, _dp, c_int64, c_double, c_int, _dp, _dp, POINTER(c_int64), POINTER(c_int64),
@@ -287,6 +288,9 @@ class Handle:
 
     def panel_apply(self, K, what):
         _chk(lib().ck_panel_apply(self._h, int(K), int(what)))
+
+    def panel_apply_sigma(self, K, J_lo, J_hi):
+        _chk(lib().ck_panel_apply_sigma(self._h, int(K), int(J_lo), int(J_hi)))
 
     def aux_finish(self):
         pred, err = np.empty(self._m), np.empty(self._m)

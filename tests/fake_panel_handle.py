@@ -75,16 +75,21 @@ class FakePanelHandle:
         P[:NB] = L
         P[NB:] = np.linalg.solve(L, P[NB:].T).T
 
+    def panel_apply_sigma(self, K, J_lo, J_hi):
+        NB = self.NB
+        P = self.panel_tensor(K).numpy().reshape(-1, NB)
+        for J in range(max(J_lo, K + 1), min(J_hi, self.nK - 1) + 1):
+            if J % self.world != self.rank:
+                continue
+            C = self.sig[J].numpy().reshape(-1, NB)
+            A = P[(J - K) * NB:]
+            C -= A @ A[:NB].T
+
     def panel_apply(self, K, what):
         NB = self.NB
         P = self.panel_tensor(K).numpy().reshape(-1, NB)
         if what & 1:
-            for J in range(K + 1, self.nK):
-                if J % self.world != self.rank:
-                    continue
-                C = self.sig[J].numpy().reshape(-1, NB)
-                A = P[(J - K) * NB:]
-                C -= A @ A[:NB].T
+            self.panel_apply_sigma(K, K + 1, self.nK - 1)
         if what & 2:
             L = np.tril(P[:NB])
             XK = np.linalg.solve(L, self.X[:, K * NB:(K + 1) * NB].T).T

@@ -31,10 +31,10 @@ def _worker(rank, world, port, case, q):
     try:
         from sif_xco2_cokriging_amd.distributed import DistributedJoint
         from tests.fake_panel_handle import FakePanelHandle
-        if case == "solve":
+        if case in ("solve", "solve_sequential"):
             g = load_golden("joint_solve")
             h = FakePanelHandle(g["params_A"], [g["coords0_A"], g["coords1_A"]], [g["values0_A"], g["values1_A"]], 0)
-            r = DistributedJoint(h, rank, world, dist_module=dist).prepare(len(g["pcoords_A"]))
+            r = DistributedJoint(h, rank, world, dist_module=dist, lookahead=(case == "solve")).prepare(len(g["pcoords_A"]))
             pred, err = r.predict(1, g["pcoords_A"])
             q.put((rank, "ok", pred, err))
         else:
@@ -72,10 +72,12 @@ def _run(world, case):
     return sorted(out, key=lambda t: t[0])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_joint_predict_two_ranks(world):
+@pytest.mark.parametrize("world,case", [(2, "solve"), (3, "solve"), (2, "solve_sequential")])
+def test_joint_predict_two_ranks(world, case):
+    """look-ahead schedule (asynchronous broadcast of panel K + 1 under the update by panel K) and the
+    plain factor -> broadcast -> apply sequence"""
     g = load_golden("joint_solve")
-    out = _run(world, "solve")
+    out = _run(world, case)
     for rank, status, pred, err in out:
         assert status == "ok"
         assert np.max(np.abs(pred - g["pred_A_1"])) / np.max(np.abs(g["pred_A_1"])) < 1e-9

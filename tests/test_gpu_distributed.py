@@ -19,10 +19,15 @@ class _GlooViaHost:
     def __init__(self, dist):
         self.d = dist
 
-    def broadcast(self, t, src, group=None):
+    def broadcast(self, t, src, group=None, async_op=False):
         c = t.cpu()
         self.d.broadcast(c, src=src)
         t.copy_(c)
+        if async_op:
+            class _Done:
+                def wait(self):
+                    return True
+            return _Done()
 
     def all_gather(self, outs, t, group=None):
         cs = [o.cpu() for o in outs]
@@ -31,7 +36,7 @@ class _GlooViaHost:
             o.copy_(c)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, via_host):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -56,14 +61,16 @@ def _worker(rank, world, port, q):
             h.set_data(k, coords[k], values[k])
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
-        r = DistributedJoint(h, rank, world, dist_module=_GlooViaHost(dist), device=dev).prepare(len(g["pcoords_A"]))
+        dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
+        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev).prepare(len(g["pcoords_A"]))
         pred, err = r.predict(0, g["pcoords_A"])
         q.put((rank, pred, err, coords, values))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_matches_oracle():
+@pytest.mark.parametrize("via_host", [True, False])
+def test_two_ranks_one_gpu_matches_oracle(via_host):
     import torch.multiprocessing as mp
     from oracle import cokrige_oracle as orc
     s = socket.socket()
@@ -72,7 +79,7 @@ def test_two_ranks_one_gpu_matches_oracle():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, via_host)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _queue
