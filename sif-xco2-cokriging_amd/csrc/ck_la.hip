@@ -895,6 +895,145 @@ struct CkSrcAux {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// The 8-wave multi-panel tile with LDS-DMA staging (option "gemm_variant" = 7)
+// ---------------------------------------------------------------------------------------
+// gemm_tile_m<8, 128> moves every operand byte global -> VGPR -> (negate) -> ds_write -> LDS and
+// waits for the writes in front of each barrier.  Here the next chunk goes global -> LDS directly
+// (global_load_lds_dwordx4: one wave instruction fills 8 whole 128-byte rows, 1 KB linear in LDS;
+// the row-image swizzle is applied on the GLOBAL side: lane (row r8, slot sj) fetches pair
+// sj ^ ((row >> 1) & 7), so the global side stays one full line per row).  No staging registers, no
+// ds_write, no sign flips in the loop: the accumulators start as -C and are stored as -acc.
+// The freed registers hold the second half-chunk's fragments, read under the first half's MFMAs.
+template <class SRC>
+__device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
+                                            char* lds) {
+    constexpr int BOFF = 128 * 128;
+    constexpr int STAGE = 256 * 128;
+    constexpr int NST = CK_NB / GEMM_BK;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int li = lane & 15, g = lane >> 4;
+
+    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
+    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * 32 + li) * 8u;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int slot = (4 * kb + g) ^ (li >> 1);
+        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
+        b_rd[kb] = BOFF + (wn * 32 + li) * 128 + slot * 16;
+    }
+    // DMA duty of wave w: image rows [32 w, 32 w + 32) -- A rows for w < 4, B rows for w >= 4 --
+    // as 4 instructions of 8 rows; lane -> (row r8 = lane >> 3, slot sj = lane & 7)
+    const int r8 = lane >> 3, sj = lane & 7;
+    const unsigned d_row = (unsigned)((32 * (w & 3) + r8) * CK_NB) * 8u;
+    const unsigned d_even = d_row + 16u * (unsigned)(sj ^ (r8 >> 1));
+    const unsigned d_odd = d_row + 16u * (unsigned)(sj ^ (r8 >> 1) ^ 4);
+    char* const lds_w = lds + 32 * w * 128;
+
+    const ck_gchar *Ab, *Bb;
+    src.get(0, Ab, Bb);
+#define CK_DMA_CHUNK(stage_, kbyte_)                                                                            \
+    {                                                                                                           \
+        const ck_gchar* gb_ = (w < 4 ? Ab : Bb) + (kbyte_);                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
+            const unsigned vo_ = ((t & 1) ? d_odd : d_even) + (unsigned)(8 * t * CK_NB) * 8u;                   \
+            __builtin_amdgcn_global_load_lds((ck_glb_void*)(gb_ + vo_),                                         \
+                                             (ck_lds_void*)(lds_w + (stage_) * STAGE + t * 1024), 16, 0, 0);    \
+        }                                                                                                       \
+    }
+    CK_DMA_CHUNK(0, 0L);
+    d4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j][r] = -*reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
+        }
+    __builtin_amdgcn_s_waitcnt(0);   // C and the first chunk have landed
+    __syncthreads();
+
+    // (Tried: the chunk's barrier in the middle of its MFMAs with a second fragment set, so that every
+    // LDS read is issued 16 MFMAs before its use -- correct, 3 % slower than this plain order.)
+    const int nst = np * NST;
+    int pnl = 0, kc = 0;             // panel and chunk-in-panel of the chunk being PREFETCHED
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) {
+            if (++kc == NST) {
+                kc = 0;
+                src.get(++pnl, Ab, Bb);
+            }
+            CK_DMA_CHUNK(cur ^ 1, (long)kc * (GEMM_BK * 8));
+        }
+        const char* sb = lds + cur * STAGE;
+        d2_t af[2][4], bf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[kb][i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb][i][h], bf[kb][j][h], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next chunk is in LDS
+        __syncthreads();
+    }
+#undef CK_DMA_CHUNK
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = -acc[i][j][r];
+        }
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restrict__ sigptr, int K0, int np, int J0,
+                                                         long Npad) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = J0 + (int)blockIdx.y;
+    const long M = Npad - (long)J * CK_NB;
+    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if (r0 + 127 < c0) return;
+    const CkSrcSyrk src{sigptr, K0, J, r0, c0};
+    gemm_tile_d(sigptr[J], CK_NB, src, np, r0, c0, lds);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 4) void k_aux_group_d(double* __restrict__ aux, long mpad,
+                                                        double* const* __restrict__ sigptr, int K0, int np, int J0) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = J0 + (int)blockIdx.y;
+    const int tiles_n = CK_NB / 128;
+    const int nblk = (int)(mpad / 128) * tiles_n;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
+    gemm_tile_d(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
+}
+
 // block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
 template <int WAVES, int TN>
 __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_syrk_group(
@@ -936,6 +1075,11 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int 
         k_syrk_group<4, 64><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
         return;
     }
+    if (g_ck_gemm_variant == 7) {
+        const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
+        k_syrk_group_d<0><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+        return;
+    }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
     if (g_ck_gemm_variant == 4)
         k_syrk_group<4, 128><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
@@ -949,6 +1093,11 @@ void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const
     if (g_ck_gemm_variant == 6) {
         const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 64)), (unsigned)nJ);
         k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        return;
+    }
+    if (g_ck_gemm_variant == 7) {
+        const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
+        k_aux_group_d<0><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         return;
     }
     const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
@@ -1006,14 +1155,14 @@ __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restric
         gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
-int g_ck_gemm_variant = 5;   // 5: 128x128 tiles, 8 waves of 64x32, two workgroups per CU (default); 4: the same with 4 waves of 64x64; 0: 256x128 plane/XOR image; 1: padded rows + b64 reads; 2: ping-pong + LDS-DMA
+int g_ck_gemm_variant = 7;   // 7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default; the per-panel kernels of the multi-GPU path use form 5); 5: the same staged through registers; 4: 4 waves of 64x64; 6: 128x64 tiles, three workgroups per CU; 0: 256x128 plane/XOR image; 1: padded rows + b64 reads; 2: ping-pong + LDS-DMA
 
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
                        int64_t sC, int64_t sA, int64_t sB) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
     const int v = g_ck_gemm_variant;
-    if ((v == 5 || v == 6) && N % 128 == 0) {
+    if ((v == 5 || v == 6 || v == 7) && N % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
                                                              sC, sA, sB);
@@ -1064,7 +1213,7 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
     if (nJ <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
-    if (g_ck_gemm_variant == 5 || g_ck_gemm_variant == 6) {
+    if (g_ck_gemm_variant == 5 || g_ck_gemm_variant == 6 || g_ck_gemm_variant == 7) {
         k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
         return;

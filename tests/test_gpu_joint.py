@@ -98,7 +98,7 @@ def test_cov_dense_blocks(native, tag):
         np.testing.assert_allclose(c0, g[f"c0_{tag}_{i}"], rtol=5e-13, atol=1e-300)
 
 
-@pytest.mark.parametrize("variant", [5, 4, 0, 1, 2])
+@pytest.mark.parametrize("variant", [7, 5, 4, 0, 1, 2])
 def test_gemm_nt_mfma(native, variant):
     """every tile structure of the MFMA GEMM (option gemm_variant) against torch fp64"""
     import torch
@@ -120,7 +120,7 @@ def test_gemm_nt_mfma(native, variant):
         if lower:
             # tiles strictly above the diagonal are skipped (left untouched)
             BN = 128 if N % 128 == 0 else 64
-            BM = 128 if (variant in (4, 5) and N % 128 == 0) else 256
+            BM = 128 if (variant in (4, 5, 7) and N % 128 == 0) else 256
             c0 = C0.cpu().numpy()
             for tm in range(M // BM):
                 for tn in range(N // BN):
@@ -131,7 +131,7 @@ def test_gemm_nt_mfma(native, variant):
                         np.testing.assert_allclose(got[blk], ref[blk], rtol=1e-12, atol=1e-11)
         else:
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
-    h.set_option("gemm_variant", 5)
+    h.set_option("gemm_variant", 7)
 
 
 def _assembled(native, params, coords, values, metric, exact=False, site_order=None):
