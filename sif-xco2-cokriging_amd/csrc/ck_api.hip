@@ -90,6 +90,7 @@ struct ck_handle {
     int64_t fallback_total = 0;
     std::vector<double*> sig;    // per panel; nullptr if not owned
     double** d_sigptr = nullptr;
+    double** d_panelptr = nullptr;   // where panel K can be read on this rank: own storage or receive buffer K & 1
     int *d_tile0 = nullptr, *d_panel_of = nullptr;   // assembly launch map of the owned panels
     int n_owned = 0, total_tiles = 0;
     double* recv[2] = {nullptr, nullptr};   // receive buffers for remote panels (world > 1)
@@ -490,6 +491,12 @@ static int ensure_layout(ck_handle* h) {
             for (int b = 0; b < 2; ++b)
                 if (dev_alloc(h, (void**)&h->recv[b], Np * CK_NB * 8)) return -1;
         }
+        {
+            std::vector<double*> pp(h->nK);
+            for (int K = 0; K < h->nK; ++K) pp[K] = h->sig[K] ? h->sig[K] : h->recv[K & 1];
+            if (dev_alloc(h, (void**)&h->d_panelptr, (int64_t)h->nK * sizeof(double*))) return -1;
+            HIPCHK(hipMemcpy(h->d_panelptr, pp.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
+        }
     }
     h->layout_ready = true;
     return 0;
@@ -733,7 +740,10 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     if (J0 > Jhi) return;
     const int nJ = (Jhi - J0) / h->world + 1;
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
+    if (g_ck_gemm_variant == 7)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
+        ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad);
+    else
+        ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -757,9 +767,12 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
-                      P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
-                      h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
+    if (g_ck_gemm_variant == 7)
+        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ);
+    else
+        ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
+                          P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
+                          h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -853,14 +866,14 @@ static int factor_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_syrk_group(h->stream, h->d_sigptr, K0, g, K0 + g, 1, h->Npad);
+                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad);
                     gemm_timed_end(h);
                 }
                 panel_factor_on(h, K0 + g, h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_syrk_group(h->stream, h->d_sigptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->Npad);
+                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad);
                 gemm_timed_end(h);
             }
         }
@@ -897,14 +910,14 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_sigptr, K0, g, K0 + g, 1);
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1);
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_sigptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc);
+                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc);
                 gemm_timed_end(h);
             }
         }
@@ -1440,7 +1453,7 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     int64_t tot = 2 * al(3 * Np * 8) + al(Np * 8);
     for (int K = h->rank; K < nK; K += h->world) tot += al((Np - (int64_t)K * CK_NB) * CK_NB * 8);
-    tot += al((int64_t)nK * sizeof(double*));
+    tot += 2 * al((int64_t)nK * sizeof(double*));   // d_sigptr, d_panelptr
     if (h->world > 1) tot += 2 * al(Np * CK_NB * 8);
     const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
     tot += al(mpad * Np * 8) + 2 * al(3 * mpad * 8) + 2 * al(2 * mpad * 8);

@@ -77,7 +77,8 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // Cholesky trailing update of every owned block column J = J0 + y * Jstep (y < nJ) by panel K
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
-void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int np, int J0, int nJ, int64_t Npad);
+void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
+                          int Jstep, int nJ, int64_t Npad);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ);
 void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,

@@ -870,7 +870,9 @@ __device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, co
         }
 }
 
-// operands of the grouped Cholesky trailing update: panels K0 .. K0 + np - 1, block column J
+// operands of the grouped Cholesky trailing update: panels K0 .. K0 + np - 1, block column J.
+// sigptr[K]: where panel K can be READ on this rank (its own storage, or the receive buffer a remote
+// panel was broadcast into -- ck_api.hip: d_panelptr)
 struct CkSrcSyrk {
     double* const* sigptr;
     int K0, J;
@@ -1004,10 +1006,11 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 }
 
 template <int DUMMY>
-__global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restrict__ sigptr, int K0, int np, int J0,
-                                                         long Npad) {
+__global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restrict__ sigptr,
+                                                         double* const* __restrict__ srcptr, int K0, int np, int J0,
+                                                         int Jstep, long Npad) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int J = J0 + (int)blockIdx.y;
+    const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
     const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
     const int nblk = tiles_m * tiles_n;
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restri
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (r0 + 127 < c0) return;
-    const CkSrcSyrk src{sigptr, K0, J, r0, c0};
+    const CkSrcSyrk src{srcptr, K0, J, r0, c0};
     gemm_tile_d(sigptr[J], CK_NB, src, np, r0, c0, lds);
 }
 
@@ -1067,7 +1070,10 @@ __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) vo
     gemm_tile_m<WAVES, TN>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
 
-void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int np, int J0, int nJ, int64_t Npad) {
+// srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 (the
+// block-column-cyclic stride of a multi-process run) is served by the LDS-DMA form only
+void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
+                          int Jstep, int nJ, int64_t Npad) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     if (g_ck_gemm_variant == 6) {
@@ -1077,7 +1083,7 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, int K0, int 
     }
     if (g_ck_gemm_variant == 7) {
         const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-        k_syrk_group_d<0><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+        k_syrk_group_d<0><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
         return;
     }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
