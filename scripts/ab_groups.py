@@ -24,7 +24,8 @@ for rnd in range(3):
         h.set_option("gemm_variant", v)
         h.set_option("lookahead", la)
         h.assemble_joint()
-        assert h.factor() == 0
+        info = h.factor()
+        assert info == 0 or os.environ.get("CK_AB_NOCHECK"), info   # kernel-timing experiments produce garbage on purpose
         pred, err = h.predict(0, pb["pcoords"])
         t = h.timings()
         res.setdefault(c, []).append((t["factor_ms"], t["solve_ms"], t["syrk_ms"], t["aux_gemm_ms"], float(pred[17])))

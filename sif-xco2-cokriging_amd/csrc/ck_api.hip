@@ -740,7 +740,7 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     if (J0 > Jhi) return;
     const int nJ = (Jhi - J0) / h->world + 1;
     if (timed) gemm_timed_begin(h, st);
-    if (g_ck_gemm_variant == 7)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
+    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
         ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad);
     else
         ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
@@ -767,7 +767,7 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     if (timed) gemm_timed_begin(h, st);
-    if (g_ck_gemm_variant == 7)
+    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8)
         ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ);
     else
         ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,

@@ -907,55 +907,61 @@ struct CkSrcAux {
 // sj ^ ((row >> 1) & 7), so the global side stays one full line per row).  No staging registers, no
 // ds_write, no sign flips in the loop: the accumulators start as -C and are stored as -acc.
 // The freed registers hold the second half-chunk's fragments, read under the first half's MFMAs.
-template <class SRC>
+template <int WAVES, class SRC>
 __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
                                             char* lds) {
+    static_assert(WAVES == 8 || WAVES == 4, "8 waves of 64 x 32 or 4 waves of 64 x 64");
     constexpr int BOFF = 128 * 128;
     constexpr int STAGE = 256 * 128;
     constexpr int NST = CK_NB / GEMM_BK;
+    constexpr int WCOLS = WAVES == 8 ? 4 : 2;    // waves across the tile's columns
+    constexpr int WJ = 128 / WCOLS / 16;         // 16-column MFMA tiles per wave
+    constexpr int RPW = 256 / WAVES;             // image rows each wave stages per chunk
+    constexpr int NDMA = RPW / 8;                // DMA instructions per wave and chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = w / WCOLS, wn = w % WCOLS;
     const int li = lane & 15, g = lane >> 4;
 
     ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
-    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * 32 + li) * 8u;
+    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * (WJ * 16) + li) * 8u;
     int a_rd[2], b_rd[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int slot = (4 * kb + g) ^ (li >> 1);
         a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
-        b_rd[kb] = BOFF + (wn * 32 + li) * 128 + slot * 16;
+        b_rd[kb] = BOFF + (wn * (WJ * 16) + li) * 128 + slot * 16;
     }
-    // DMA duty of wave w: image rows [32 w, 32 w + 32) -- A rows for w < 4, B rows for w >= 4 --
-    // as 4 instructions of 8 rows; lane -> (row r8 = lane >> 3, slot sj = lane & 7)
+    // DMA duty of wave w: image rows [RPW w, RPW w + RPW) -- A rows for the first half of the waves, B rows
+    // for the second -- as NDMA instructions of 8 rows; lane -> (row r8 = lane >> 3, slot sj = lane & 7)
     const int r8 = lane >> 3, sj = lane & 7;
-    const unsigned d_row = (unsigned)((32 * (w & 3) + r8) * CK_NB) * 8u;
+    const bool stage_a = w < WAVES / 2;
+    const unsigned d_row = (unsigned)((RPW * (w % (WAVES / 2)) + r8) * CK_NB) * 8u;
     const unsigned d_even = d_row + 16u * (unsigned)(sj ^ (r8 >> 1));
     const unsigned d_odd = d_row + 16u * (unsigned)(sj ^ (r8 >> 1) ^ 4);
-    char* const lds_w = lds + 32 * w * 128;
+    char* const lds_w = lds + RPW * w * 128;
 
     const ck_gchar *Ab, *Bb;
     src.get(0, Ab, Bb);
 #define CK_DMA_CHUNK(stage_, kbyte_)                                                                            \
     {                                                                                                           \
-        const ck_gchar* gb_ = (w < 4 ? Ab : Bb) + (kbyte_);                                                     \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                         \
+        const ck_gchar* gb_ = (stage_a ? Ab : Bb) + (kbyte_);                                                   \
+        _Pragma("unroll") for (int t = 0; t < NDMA; ++t) {                                                      \
             const unsigned vo_ = ((t & 1) ? d_odd : d_even) + (unsigned)(8 * t * CK_NB) * 8u;                   \
             __builtin_amdgcn_global_load_lds((ck_glb_void*)(gb_ + vo_),                                         \
                                              (ck_lds_void*)(lds_w + (stage_) * STAGE + t * 1024), 16, 0, 0);    \
         }                                                                                                       \
     }
     CK_DMA_CHUNK(0, 0L);
-    d4_t acc[4][2];
+    d4_t acc[4][WJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][r] = -*reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
+            for (int j = 0; j < WJ; ++j) acc[i][j][r] = -*reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
         }
     __builtin_amdgcn_s_waitcnt(0);   // C and the first chunk have landed
     __syncthreads();
@@ -971,17 +977,20 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
                 kc = 0;
                 src.get(++pnl, Ab, Bb);
             }
+#ifndef CK_EXP_NODMA
             CK_DMA_CHUNK(cur ^ 1, (long)kc * (GEMM_BK * 8));
+#endif
         }
         const char* sb = lds + cur * STAGE;
-        d2_t af[2][4], bf[2][2];
+        d2_t af[2][4], bf[2][WJ];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[kb][i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
+            for (int j = 0; j < WJ; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
         }
+        if (WAVES == 4) __builtin_amdgcn_sched_barrier(0);   // both half-chunks' fragments in flight before the first MFMA
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -989,10 +998,12 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb][i][h], bf[kb][j][h], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next chunk is in LDS
+#ifndef CK_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 #undef CK_DMA_CHUNK
 #pragma unroll
@@ -1001,12 +1012,12 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         for (int r = 0; r < 4; ++r) {
             ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = -acc[i][j][r];
+            for (int j = 0; j < WJ; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = -acc[i][j][r];
         }
 }
 
-template <int DUMMY>
-__global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restrict__ sigptr,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d(double* const* __restrict__ sigptr,
                                                          double* const* __restrict__ srcptr, int K0, int np, int J0,
                                                          int Jstep, long Npad) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
@@ -1020,11 +1031,11 @@ __global__ __launch_bounds__(512, 4) void k_syrk_group_d(double* const* __restri
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (r0 + 127 < c0) return;
     const CkSrcSyrk src{srcptr, K0, J, r0, c0};
-    gemm_tile_d(sigptr[J], CK_NB, src, np, r0, c0, lds);
+    gemm_tile_d<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
 }
 
-template <int DUMMY>
-__global__ __launch_bounds__(512, 4) void k_aux_group_d(double* __restrict__ aux, long mpad,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(double* __restrict__ aux, long mpad,
                                                         double* const* __restrict__ sigptr, int K0, int np, int J0) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y;
@@ -1034,7 +1045,7 @@ __global__ __launch_bounds__(512, 4) void k_aux_group_d(double* __restrict__ aux
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
-    gemm_tile_d(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
+    gemm_tile_d<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
 
 // block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
@@ -1081,9 +1092,12 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
         k_syrk_group<4, 64><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
         return;
     }
-    if (g_ck_gemm_variant == 7) {
+    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8) {
         const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-        k_syrk_group_d<0><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
+        if (g_ck_gemm_variant == 7)
+            k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
+        else
+            k_syrk_group_d<4><<<grid, dim3(256), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
         return;
     }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
@@ -1101,9 +1115,12 @@ void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const
         k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         return;
     }
-    if (g_ck_gemm_variant == 7) {
+    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8) {
         const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-        k_aux_group_d<0><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        if (g_ck_gemm_variant == 7)
+            k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        else
+            k_aux_group_d<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         return;
     }
     const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
@@ -1168,7 +1185,7 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
                        int64_t sC, int64_t sA, int64_t sB) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
     const int v = g_ck_gemm_variant;
-    if ((v == 5 || v == 6 || v == 7) && N % 128 == 0) {
+    if ((v == 5 || v == 6 || v == 7 || v == 8) && N % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
                                                              sC, sA, sB);
@@ -1219,7 +1236,7 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
     if (nJ <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
-    if (g_ck_gemm_variant == 5 || g_ck_gemm_variant == 6 || g_ck_gemm_variant == 7) {
+    if (g_ck_gemm_variant >= 5 && g_ck_gemm_variant <= 8) {
         k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
         return;

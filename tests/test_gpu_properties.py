@@ -46,7 +46,7 @@ def test_against_oracle_n1500(shape):
         assert np.max(np.abs(err ** 2 - re ** 2)) < 1e-9
 
 
-@pytest.mark.parametrize("group,variant", [(1, 4), (3, 4), (4, 5), (16, 5), (3, 6), (2, 6), (3, 7), (4, 7)])
+@pytest.mark.parametrize("group,variant", [(1, 4), (3, 4), (4, 5), (16, 5), (3, 6), (2, 6), (3, 7), (4, 7), (3, 8)])
 def test_panel_groups_and_tile_variants(group, variant):
     """The grouped factorisation / solve (trailing updates with K = 512 G from G panel buffers, option
     panel_group) for group sizes that do and do not divide the 7 panels, on both multi-panel tile
