@@ -174,294 +174,14 @@ __device__ __forceinline__ void gemm_tile(double* __restrict__ C, long ldc, cons
         }
 }
 
-// ---------------------------------------------------------------------------------------
-// Ping-pong tile with LDS-DMA staging (option "gemm_variant" = 2)
-// ---------------------------------------------------------------------------------------
-// Same tile and the same LDS image as gemm_tile, different schedule.  The eight waves form two
-// groups, X = waves 0-3 and Y = waves 4-7 (one wave of each group per SIMD).  A K step is two
-// phases separated by workgroup barriers:
-//     phase A(s):  X issues its 64 MFMAs of step s back to back  |  Y does memory work
-//     phase B(s):  Y issues its 64 MFMAs of step s               |  X does memory work
-// One wave alone keeps the f64 MFMA pipe full (64 cycles per instruction, ck_debug_mfma_peak), so
-// the pipe never waits for LDS or global latency: those always fall into the other group's phase.
-// Global -> LDS goes by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write):
-// X streams the A tile, Y the B tile, one 64-row x 16-byte plane segment per instruction; the
-// row ^ p swizzle of the image is applied to the per-lane SOURCE address, the LDS side is linear.
-// Memory work of a phase:  wait for the DMA issued one phase pair ago, read the operand fragments
-// of the group's next MFMA phase, issue the next DMA:
-//     X in B(s): wait until only the newest K step (A(s+2)) is still in flight | fragments(s+1) | issue A(s+3)
-//     Y in A(s): wait until only the newest K step (B(s+2)) is still in flight | fragments(s)   | issue B(s+3)
-// so every DMA has two full phase pairs (>= 16k cycles) to land before anybody waits for it.
-// Three LDS stage buffers (144 KB): every DMA targets a buffer whose last readers finished at
-// least one barrier earlier.  Barriers are raw s_barrier + lgkmcnt(0): DMA stays in flight
-// across them.  A is negated when its fragments are read.
+// address-space-qualified void pointers for __builtin_amdgcn_global_load_lds
 typedef __attribute__((address_space(3))) void ck_lds_void;
 typedef const __attribute__((address_space(1))) void ck_glb_void;
 
-// LDS image of this variant ("row image"): a K step of a tile is stored row-major, 128 bytes
-// (16 k = 8 pairs) per row, the pair p of row r in 16-byte slot  p ^ ((r >> 1) & 7).
-//   - one LDS-DMA instruction fills 8 whole rows (1 KB, linear in LDS) from 8 full 128-byte
-//     global lines: 8 consecutive lanes take the 8 pairs of one row in swizzled order, so the
-//     global side is perfectly coalesced (one L2 line per row per K step);
-//   - the ds_read_b128 operand reads (fixed 16-lane groups of the hardware) touch every bank
-//     exactly once per group for this swizzle.
-template <int WN, int GROUPING>
-__device__ __forceinline__ void gemm_tile_pp(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
-                                             const double* __restrict__ B, long ldb, long r0, long c0, int K,
-                                             char* lds) {
-    constexpr int BN = WN * 32;
-    constexpr int BOFF = CK_BM * 128;            // B rows follow the 256 A rows
-    constexpr int STAGE = (CK_BM + BN) * 128;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // which four waves form a group (one wave of each group must sit on every SIMD)
-    const int grp = GROUPING == 0 ? (w >> 2) : (w & 1);
-    const int wq = GROUPING == 0 ? (w & 3) : (w >> 1);
-    const int wm = grp * 2 + (wq >> 1), wn = wq & 1;
-    const int li = lane & 15, g = lane >> 4;
-
-    const char* Ab = reinterpret_cast<const char*>(A + r0 * lda);
-    const char* Bb = reinterpret_cast<const char*>(B + c0 * ldb);
-    double* Cb = C + r0 * ldc + c0;
-    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * (WN * 16) + li) * 8u;
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int slot = (4 * kb + g) ^ (li >> 1);
-        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
-        b_rd[kb] = BOFF + (wn * (WN * 16) + li) * 128 + slot * 16;
-    }
-    // DMA duty of this wave: X wave wq -> A rows [64 wq, 64 wq + 64); Y wave wq -> B rows likewise;
-    // instruction t of 8 covers rows 64 wq + 8 t .. + 7: lane -> (row r8 = lane >> 3, slot j = lane & 7),
-    // source pair p = j ^ ((row >> 1) & 7) = j ^ (r8 >> 1) ^ (4 (t & 1)).
-    const unsigned ld_bytes = (unsigned)(grp == 0 ? lda : ldb) * 8u;
-    const int r8 = lane >> 3, sj = lane & 7;
-    const unsigned d_row = (unsigned)(64 * wq + r8) * ld_bytes;
-    const unsigned d_even = d_row + 16u * (unsigned)(sj ^ (r8 >> 1));
-    const unsigned d_odd = d_row + 16u * (unsigned)(sj ^ (r8 >> 1) ^ 4);
-    const bool dma_on = grp == 0 || 64 * wq < BN;
-    const int nst = K / GEMM_BK;
-
-    d2_t fa[2][4], fb[2][WN];
-    d4_t acc[4][WN];
-
-#define PP_DMA(step)                                                                                       \
-    if (dma_on) {                                                                                          \
-        const char* gb_ = (grp == 0 ? Ab : Bb) + (long)(step) * (GEMM_BK * 8);                             \
-        char* lb_ = lds + ((step) % 3) * STAGE + (grp == 0 ? 0 : BOFF) + 64 * wq * 128;                   \
-        unsigned de_ = d_even, do_ = d_odd;                                                                \
-        asm volatile("" : "+v"(de_), "+v"(do_));   /* keep the address arithmetic inside the phase */      \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                    \
-            const unsigned vo_ = ((t & 1) ? do_ : de_) + (unsigned)(8 * t) * ld_bytes;                     \
-            __builtin_amdgcn_global_load_lds((ck_glb_void*)(gb_ + vo_), (ck_lds_void*)(lb_ + t * 1024), 16, 0, 0); \
-        }                                                                                                  \
-    }
-#define PP_FRAGS(step)                                                                                     \
-    {                                                                                                      \
-        const char* sb_ = lds + ((step) % 3) * STAGE;                                                      \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[kb][i] = -*reinterpret_cast<const d2_t*>(sb_ + a_rd[kb] + i * 2048); \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j) fb[kb][j] = *reinterpret_cast<const d2_t*>(sb_ + b_rd[kb] + j * 2048); \
-        }                                                                                                  \
-    }
-#define PP_MFMA()                                                                               \
-    {                                                                                           \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                        \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
-        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kb][i][h], fb[kb][j][h], acc[i][j], 0, 0, 0); \
-    }
-#define PP_BARRIER()                                   \
-    {                                                  \
-        __builtin_amdgcn_sched_barrier(0);             \
-        __builtin_amdgcn_s_waitcnt(0xC07F);            \
-        __builtin_amdgcn_s_barrier();                  \
-        __builtin_amdgcn_sched_barrier(0);             \
-    }
-    /* The DMA of K step s+1 must have landed.  While a newer K step (s+2) is in flight behind it,  \
-       "all but the newest 8" says exactly that; at the tail nothing newer was issued, so drain. */ \
-#define PP_VMWAIT(step)                                \
-    {                                                  \
-        if ((step) + 2 < nst)                          \
-            __builtin_amdgcn_s_waitcnt(0x0F78);        \
-        else                                           \
-            __builtin_amdgcn_s_waitcnt(0x0F70);        \
-        __builtin_amdgcn_sched_barrier(0);             \
-    }
-
-    // ---- prologue ----
-    if (grp == 0) {
-        PP_DMA(0);
-        if (nst > 1) PP_DMA(1);
-        if (nst > 2) PP_DMA(2);
-    } else {
-        PP_DMA(0);
-        if (nst > 1) PP_DMA(1);
-        if (nst > 2) PP_DMA(2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const char* rowp = reinterpret_cast<const char*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowp + j * 128 + c_off);
-        }
-    __builtin_amdgcn_s_waitcnt(0);      // everything landed: nothing pending enters the loops
-    PP_BARRIER();
-
-    // Two role-specialised loops (no register copies at control-flow joins); both execute exactly
-    // two barriers per K step, which is all s_barrier counts.
-    if (grp == 0) {
-        PP_FRAGS(0);
-        for (int s = 0; s < nst; ++s) {
-            PP_MFMA();                        // phase A(s)
-            PP_BARRIER();
-            PP_VMWAIT(s);                     // phase B(s): A(s+1) landed; A(s+2), issued in B(s-1), may still fly
-            if (s + 1 < nst) PP_FRAGS(s + 1);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 3 < nst) PP_DMA(s + 3);
-            PP_BARRIER();
-        }
-    } else {
-        for (int s = 0; s < nst; ++s) {
-            PP_VMWAIT(s);                     // phase A(s): B(s+1) landed; B(s+2), issued in A(s-1), may still fly
-            PP_FRAGS(s);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 3 < nst) PP_DMA(s + 3);
-            PP_BARRIER();
-            PP_MFMA();                        // phase B(s)
-            PP_BARRIER();
-        }
-    }
-#undef PP_DMA
-#undef PP_FRAGS
-#undef PP_MFMA
-#undef PP_BARRIER
-#undef PP_VMWAIT
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            char* rowp = reinterpret_cast<char*>(Cb + (long)(i * 16 + 4 * r) * ldc);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) *reinterpret_cast<double*>(rowp + j * 128 + c_off) = acc[i][j][r];
-        }
-}
-
-// ---- previous tile structure, kept for A/B measurements (option "gemm_variant" = 1) ----------
-#define GEMM_LDK 18
-
-template <int WN>
-__device__ __forceinline__ void gemm_tile_v1(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
-                                          const double* __restrict__ B, long ldb, long r0, long c0, int K,
-                                          double* lds) {
-    constexpr int BN = WN * 32;
-    constexpr int BCH = BN * 8 / 512;  // 16-byte chunks of the B tile per thread (2 or 1)
-    constexpr int STAGE = (CK_BM + BN) * GEMM_LDK;   // doubles per LDS stage: A tile then B tile
-    constexpr int BOFF = CK_BM * GEMM_LDK;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int li = lane & 15, kq = lane >> 4;
-
-    // global -> register staging assignments (one 16-byte chunk = 2 doubles of K)
-    const double* a_src[4];
-    int a_dst[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
-        a_src[u] = A + (r0 + row) * lda + ch * 2;
-        a_dst[u] = row * GEMM_LDK + ch * 2;
-    }
-    const double* b_src[BCH];
-    int b_dst[BCH];
-#pragma unroll
-    for (int u = 0; u < BCH; ++u) {
-        const int id = tid + 512 * u, row = id >> 3, ch = id & 7;
-        b_src[u] = B + (c0 + row) * ldb + ch * 2;
-        b_dst[u] = row * GEMM_LDK + ch * 2;
-    }
-
-    d4_t acc[4][WN];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-
-    d2_t ra[4], rb[BCH];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u]);
-#pragma unroll
-    for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(lds + a_dst[u]) = ra[u];
-#pragma unroll
-    for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(lds + BOFF + b_dst[u]) = rb[u];
-    __syncthreads();
-
-    const int nst = K / GEMM_BK;
-    const int a_rd = (wm * 64 + li) * GEMM_LDK + kq;
-    const int b_rd = (wn * (WN * 16) + li) * GEMM_LDK + kq;
-
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        const bool more = (st + 1 < nst);
-        if (more) {
-            const int k0 = (st + 1) * GEMM_BK;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const d2_t*>(a_src[u] + k0);
-#pragma unroll
-            for (int u = 0; u < BCH; ++u) rb[u] = *reinterpret_cast<const d2_t*>(b_src[u] + k0);
-        }
-        const double* as = lds + cur * STAGE + a_rd;
-        const double* bs = lds + cur * STAGE + BOFF + b_rd;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[WN];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = as[i * 16 * GEMM_LDK + kk * 4];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = bs[j * 16 * GEMM_LDK + kk * 4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            double* nx = lds + (cur ^ 1) * STAGE;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2_t*>(nx + a_dst[u]) = ra[u];
-#pragma unroll
-            for (int u = 0; u < BCH; ++u) *reinterpret_cast<d2_t*>(nx + BOFF + b_dst[u]) = rb[u];
-        }
-        __syncthreads();
-    }
-
-    // epilogue: C -= acc.  Register r of lane l is D[(l >> 4) + 4 r][l & 15].
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const long col = c0 + wn * (WN * 16) + j * 16 + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = r0 + wm * 64 + i * 16 + kq + 4 * r;
-                double* p = C + row * ldc + col;
-                *p = *p - acc[i][j][r];
-            }
-        }
-    }
-}
-
+// (Two further schedules of the 256 x 128 tile were measured and removed: padded LDS rows with
+// compiler-merged ds_read2_b64 operand reads -- 42 % of the LDS cycles were bank conflicts, 51.7 TF --
+// and a ping-pong schedule, two wave groups alternating MFMA and memory phases over three LDS-DMA
+// staged buffers, 48.5 TF.  DESIGN.md section 5 has the numbers.)
 
 // XCD-aware bijective remap of a 1-D block id: blocks b and b + 8 share an XCD (and its L2);
 // give each XCD a contiguous run of tiles so that neighbouring tiles (same A rows) meet in one L2.
@@ -1131,35 +851,30 @@ void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const
 }
 
 // plain (optionally batched over blockIdx.y) form
-template <int WN, int VAR>
+template <int WN>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long ldc, const double* __restrict__ A,
                                                      long lda, const double* __restrict__ B, long ldb, int tiles_m,
                                                      int tiles_n, int K, int lower, long diag_off, long sC, long sA,
                                                      long sB) {
     constexpr int BN = WN * 32;
-    __shared__ __attribute__((aligned(16))) char lds[VAR == 1 ? 2 * (CK_BM + BN) * GEMM_LDK * 8 : (VAR >= 2 ? 3 * (CK_BM + BN) * 128 : 2 * 8 * (CK_BM + BN) * 16)];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * (CK_BM + BN) * 16];
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * CK_BM, c0 = (long)tn * BN;
     if (lower && r0 + (CK_BM - 1) + diag_off < c0) return;
     const long y = blockIdx.y;
-    if (VAR == 1)
-        gemm_tile_v1<WN>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, (double*)lds);
-    else if (VAR >= 2)
-        gemm_tile_pp<WN, VAR - 2>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
-    else
-        gemm_tile<WN>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
+    gemm_tile<WN>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
 }
 
 // Trailing update of the Cholesky for ALL locally owned block columns J > K in one launch:
 //   sig[J] (rows J*NB.., NB cols) -= P[(J-K)*NB.., :] * P[(J-K)*NB .. (J-K+1)*NB, :]^T
 // where P is the factored panel K (rows K*NB.. of L, NB columns, ld = NB).
 // blockIdx.y enumerates the owned J = J0 + y * Jstep; blockIdx.x the tiles of the largest one.
-template <int VAR>
+template <int DUMMY>
 __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restrict__ sigptr,
                                                          const double* __restrict__ P, int K, int J0, int Jstep,
                                                          long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[VAR == 1 ? 2 * (CK_BM + 128) * GEMM_LDK * 8 : (VAR >= 2 ? 3 * (CK_BM + 128) * 128 : 2 * 8 * (CK_BM + 128) * 16)];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * (CK_BM + 128) * 16];
     const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
     const int tiles_m = (int)(M / CK_BM), tiles_n = CK_NB / 128;
@@ -1170,15 +885,13 @@ __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restric
     const long r0 = (long)tm * CK_BM, c0 = (long)tn * 128;
     if (r0 + (CK_BM - 1) < c0) return;
     const double* A = P + (long)(J - K) * CK_NB * CK_NB;
-    if (VAR == 1)
-        gemm_tile_v1<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, (double*)lds);
-    else if (VAR >= 2)
-        gemm_tile_pp<4, VAR - 2>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
-    else
-        gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
+    gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
-int g_ck_gemm_variant = 7;   // 7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default; the per-panel kernels of the multi-GPU path use form 5); 5: the same staged through registers; 4: 4 waves of 64x64; 6: 128x64 tiles, three workgroups per CU; 0: 256x128 plane/XOR image; 1: padded rows + b64 reads; 2: ping-pong + LDS-DMA
+// 7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default); 5: the same staged
+// through registers; 4: 4 waves of 64x64 through registers; 8: 4 waves of 64x64, LDS-DMA; 6: 128x64 tiles, three
+// workgroups per CU; 0: one 256x128 workgroup per CU
+int g_ck_gemm_variant = 7;
 
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
@@ -1200,34 +913,12 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
     const int tiles_m = (int)(M / CK_BM);
     if (N % 128 == 0) {
         const int tiles_n = (int)(N / 128);
-        dim3 grid(tiles_m * tiles_n, batch);
-        if (v == 1)
-            k_gemm_nt<4, 1><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else if (v == 2)
-            k_gemm_nt<4, 2><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else if (v == 3)
-            k_gemm_nt<4, 3><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else
-            k_gemm_nt<4, 0><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-    } else {
+        k_gemm_nt<4><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K,
+                                                                        lower, diag_off, sC, sA, sB);
+    } else {   // narrow right-hand sides (N a multiple of 64 only): the panel-internal K = 64 updates
         const int tiles_n = (int)(N / 64);
-        dim3 grid(tiles_m * tiles_n, batch);
-        if (v == 1)
-            k_gemm_nt<2, 1><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else if (v == 2)
-            k_gemm_nt<2, 2><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else if (v == 3)
-            k_gemm_nt<2, 3><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
-        else
-            k_gemm_nt<2, 0><<<grid, dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K, lower,
-                                                       diag_off, sC, sA, sB);
+        k_gemm_nt<2><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K,
+                                                                        lower, diag_off, sC, sA, sB);
     }
 }
 
@@ -1246,14 +937,7 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
                                                                                       Npad);
         return;
     }
-    if (g_ck_gemm_variant == 1)
-        k_syrk_panels<1><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
-    else if (g_ck_gemm_variant == 2)
-        k_syrk_panels<2><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
-    else if (g_ck_gemm_variant == 3)
-        k_syrk_panels<3><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
-    else
-        k_syrk_panels<0><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
+    k_syrk_panels<0><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
 }
 
 // ---------------------------------------------------------------------------------------
