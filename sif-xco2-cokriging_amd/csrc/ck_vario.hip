@@ -14,8 +14,8 @@
 // can place the edges: pass 1 finds the two extreme pairs (their distances are then recomputed
 // with the full-accuracy formula), pass 2 bins.
 //
-// Pass 2 layout: one workgroup = 256 "i" points in registers x chunks of 1024 "j" points staged
-// in LDS and broadcast; each lane owns a private histogram (sum f64 + count u32 per bin) in LDS,
+// Pass 2 layout: one workgroup = 256 "i" points in registers x chunks of 1024 "j" points that are
+// the same for every lane and therefore come through scalar loads; each lane owns a private histogram (sum f64 + count u32 per bin) in LDS,
 // laid out [bin][lane] so that the 64 lanes of a wave always hit distinct banks whatever bins
 // they choose: no atomics, no conflicts, deterministic sums.  Workgroups walk the tile list with
 // a fixed stride and write one partial histogram each; a second kernel adds the partials in a
@@ -26,6 +26,7 @@
 #define VG_JCHUNK 1024
 #define VG_MAXBINS 36
 #define VG_LUT 8192
+#define VG_G 8           // pairs per lane processed together (k_vario_bin); 16 measured slower
 
 struct VarioPartialExt {
     double rmin, rmax;
@@ -71,7 +72,6 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
                                                           const double* __restrict__ ju1,
                                                           const double* __restrict__ ju2, long nj, double rcap,
                                                           VarioPartialExt* __restrict__ part) {
-    __shared__ double sj[3][VG_JCHUNK];
     __shared__ double red_r[VG_TPB];
     __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
     const int tid = threadIdx.x;
@@ -82,37 +82,27 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
-        __syncthreads();
-        for (int k = tid; k < VG_JCHUNK; k += VG_TPB) {
-            const long j = j0 + k;
-            const bool ok = j < nj;
-            sj[0][k] = ok ? ju0[j] : 0.0;
-            sj[1][k] = ok ? ju1[j] : 0.0;
-            sj[2][k] = ok ? ju2[j] : 0.0;
-        }
-        __syncthreads();
         const long i = i0 + tid;
-        if (i < ni) {
-            const double ax = iu0[i], ay = iu1[i], az = iu2[i];
-            const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
-            long kbeg = 0;
-            if (same) {
-                kbeg = i + 1 - j0;
-                if (kbeg < 0) kbeg = 0;
-            }
-            for (long k = kbeg; k < jend; ++k) {
-                const double r = pair_r(metric, ax, ay, az, sj[0][k], sj[1][k], sj[2][k]);
-                if (r <= rcap) {
-                    if (r > rmax) {
-                        rmax = r;
-                        imax = i;
-                        jmax = j0 + k;
-                    }
-                    if (r > 0.0 && r < rmin) {
-                        rmin = r;
-                        imin = i;
-                        jmin = j0 + k;
-                    }
+        const bool live = i < ni;
+        const long ic = live ? i : ni - 1;
+        const double ax = iu0[ic], ay = iu1[ic], az = iu2[ic];
+        const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
+        const long kbeg = same ? (i + 1 - j0) : 0;        // per lane
+        long k0 = same ? (i0 + 1 - j0) : 0;               // uniform: the "j" point comes through scalar loads
+        if (k0 < 0) k0 = 0;
+#pragma unroll 8
+        for (long k = k0; k < jend; ++k) {
+            const double r = pair_r(metric, ax, ay, az, ju0[j0 + k], ju1[j0 + k], ju2[j0 + k]);
+            if (live && k >= kbeg && r <= rcap) {
+                if (r > rmax) {
+                    rmax = r;
+                    imax = i;
+                    jmax = j0 + k;
+                }
+                if (r > 0.0 && r < rmin) {
+                    rmin = r;
+                    imin = i;
+                    jmin = j0 + k;
                 }
             }
         }
@@ -174,68 +164,87 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
                                                        const unsigned char* __restrict__ lut, double inv_cell,
                                                        double* __restrict__ part_sum,
                                                        unsigned long long* __restrict__ part_cnt) {
-    __shared__ double sj[4][VG_JCHUNK];
-    __shared__ double hsum[VG_MAXBINS][VG_TPB];
-    __shared__ unsigned int hcnt[VG_MAXBINS][VG_TPB];
+    __shared__ double hsum[VG_MAXBINS + 1][VG_TPB];        // + 1: the trash row of pairs that are not retained
+    __shared__ unsigned int hcnt[VG_MAXBINS + 1][VG_TPB];
     __shared__ double sthr[VG_MAXBINS + 2];
     __shared__ unsigned char slut[VG_LUT];
     const int tid = threadIdx.x;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b <= nb; ++b) {
         hsum[b][tid] = 0.0;
         hcnt[b][tid] = 0u;
     }
     for (int k = tid; k <= nb; k += VG_TPB) sthr[k] = thr[k];
     for (int k = tid; k < VG_LUT; k += VG_TPB) slut[k] = lut[k];
+    __syncthreads();
     const double rtop = thr[nb];
+    // one group of VG_G consecutive "j" points for this lane's "i" point (see the comment in the loop)
+#define VG_GROUP8(FULL)                                                                                         \
+    {                                                                                                           \
+        double r[VG_G], bv[VG_G];                                                                                     \
+        int b[VG_G];                                                                                               \
+        bool keep[VG_G];                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < VG_G; ++u) {                                                         \
+            const long kk = (FULL) ? kg + u : (kg + u < jend ? kg + u : jend - 1);                              \
+            r[u] = pair_r(metric, ax, ay, az, ju0[j0 + kk], ju1[j0 + kk], ju2[j0 + kk]);                        \
+            bv[u] = jv[j0 + kk];                                                                                \
+            keep[u] = live && ((FULL) || kg + u < jend) && kg + u >= kbeg && r[u] <= rcap && r[u] <= rtop;      \
+            int c = (int)(fmin(r[u], rtop) * inv_cell);                                                         \
+            c = c < VG_LUT - 1 ? c : VG_LUT - 1;                                                                \
+            b[u] = slut[c];                                                                                     \
+        }                                                                                                       \
+        _Pragma("unroll") for (int pass = 0; pass < 2; ++pass) { /* up to two edges inside one r-cell */        \
+            double e[VG_G];                                                                                        \
+            _Pragma("unroll") for (int u = 0; u < VG_G; ++u) e[u] = sthr[b[u] + 1];                                \
+            _Pragma("unroll") for (int u = 0; u < VG_G; ++u) {                                                     \
+                b[u] += (r[u] > e[u]) ? 1 : 0;                                                                  \
+                b[u] = b[u] < nb - 1 ? b[u] : nb - 1;                                                           \
+            }                                                                                                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < VG_G; ++u) {                                                         \
+            double cl;                                                                                          \
+            if (covariogram) {                                                                                  \
+                cl = av * bv[u]; /* fields.py:382-383 */                                                        \
+            } else {                                                                                            \
+                const double df = av - bv[u]; /* fields.py:384-385 */                                           \
+                cl = 0.5 * (df * df);                                                                           \
+            }                                                                                                   \
+            const int bb = keep[u] ? b[u] : nb;                                                                 \
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&hsum[bb][tid],      \
+                                                keep[u] ? cl : 0.0);                                            \
+            atomicAdd(&hcnt[bb][tid], keep[u] ? 1u : 0u);                                                       \
+        }                                                                                                       \
+    }
     const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     // per-lane 64-bit count spill: hcnt is 32-bit, a lane sees at most nJ * VG_JCHUNK pairs per I block
     for (long t = blockIdx.x; t < nI * nJ; t += gridDim.x) {
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
-        __syncthreads();
-        for (int k = tid; k < VG_JCHUNK; k += VG_TPB) {
-            const long j = j0 + k;
-            const bool ok = j < nj;
-            sj[0][k] = ok ? ju0[j] : 0.0;
-            sj[1][k] = ok ? ju1[j] : 0.0;
-            sj[2][k] = ok ? ju2[j] : 0.0;
-            sj[3][k] = ok ? jv[j] : 0.0;
-        }
-        __syncthreads();
         const long i = i0 + tid;
-        if (i < ni) {
-            const double ax = iu0[i], ay = iu1[i], az = iu2[i], av = iv[i];
-            const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
-            long kbeg = 0;
-            if (same) {
-                kbeg = i + 1 - j0;
-                if (kbeg < 0) kbeg = 0;
-            }
-            for (long k = kbeg; k < jend; ++k) {
-                const double r = pair_r(metric, ax, ay, az, sj[0][k], sj[1][k], sj[2][k]);
-                if (r <= rcap && r <= rtop) {
-                    int c = (int)(r * inv_cell);
-                    c = c < VG_LUT - 1 ? c : VG_LUT - 1;
-                    int b = slut[c];
-                    b += (r > sthr[b + 1]) ? 1 : 0;     // up to two edges inside one r-cell
-                    b = b < nb - 1 ? b : nb - 1;
-                    b += (r > sthr[b + 1]) ? 1 : 0;
-                    b = b < nb - 1 ? b : nb - 1;
-                    const double bv = sj[3][k];
-                    double cl;
-                    if (covariogram) {
-                        cl = av * bv;                 // fields.py:382-383
-                    } else {
-                        const double df = av - bv;    // fields.py:384-385
-                        cl = 0.5 * (df * df);
-                    }
-                    hsum[b][tid] += cl;
-                    hcnt[b][tid] += 1u;
-                }
-            }
-        }
+        const bool live = i < ni;
+        const long ic = live ? i : ni - 1;
+        const double ax = iu0[ic], ay = iu1[ic], az = iu2[ic], av = iv[ic];
+        const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
+        // The "j" point is the same for every lane of the workgroup: its coordinates and value come
+        // through SCALAR loads (uniform address, 8 points per s_load_dwordx16 once unrolled) and sit
+        // in SGPRs -- no LDS staging, no LDS reads in the pair loop.  In the triangular (same) case
+        // the loop starts at the first column any lane of the block needs; each lane masks k < kbeg.
+        const long kbeg = same ? (i + 1 - j0) : 0;                     // per lane
+        long k0 = same ? (i0 + 1 - j0) : 0;                            // uniform
+        if (k0 < 0) k0 = 0;
+        // VG_G pairs at a time, in stages, so that the three dependent LDS lookups of a pair (r-cell
+        // -> bin, then up to two edge fix-ups) are each issued for all eight before the first result
+        // is needed; at one wave per SIMD (the private histograms fill the LDS) a pair-by-pair loop
+        // pays those round trips one after the other -- hipcc does not software-pipeline them.  The
+        // histogram update is a fire-and-forget LDS add into this lane's own slot (ds_add_f64 /
+        // ds_add_u32): sequential per lane in program order, hence deterministic; pairs that are not
+        // retained add 0 to a trash row (index nb).
+        long kg = k0;
+        for (; kg + VG_G <= jend; kg += VG_G)      // full groups: consecutive scalar loads merge into s_load_dwordx16
+            VG_GROUP8(true);
+        for (; kg < jend; kg += VG_G) VG_GROUP8(false);   // tail: indices clamped, pairs beyond jend masked
     }
+#undef VG_GROUP8
     __syncthreads();
     // reduce the 256 private histograms: thread b sums bin b in lane order (deterministic)
     if (tid < nb) {
