@@ -469,7 +469,7 @@ static int ensure_layout(ck_handle* h) {
         h->sig.assign(h->nK, nullptr);
         for (int K = h->rank; K < h->nK; K += h->world) {
             const int64_t rows = Np - (int64_t)K * CK_NB;
-            if (dev_alloc(h, (void**)&h->sig[K], rows * CK_NB * 8)) return -1;
+            if (dev_alloc(h, (void**)&h->sig[K], (rows * CK_NB + CK_PANEL_TAIL) * 8)) return -1;
         }
         if (dev_alloc(h, (void**)&h->d_sigptr, (int64_t)h->nK * sizeof(double*))) return -1;
         HIPCHK(hipMemcpy(h->d_sigptr, h->sig.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
@@ -489,7 +489,7 @@ static int ensure_layout(ck_handle* h) {
         HIPCHK(hipMemcpy(h->d_panel_of, panel_of.data(), panel_of.size() * sizeof(int), hipMemcpyHostToDevice));
         if (h->world > 1) {
             for (int b = 0; b < 2; ++b)
-                if (dev_alloc(h, (void**)&h->recv[b], Np * CK_NB * 8)) return -1;
+                if (dev_alloc(h, (void**)&h->recv[b], (Np * CK_NB + CK_PANEL_TAIL) * 8)) return -1;
         }
         {
             std::vector<double*> pp(h->nK);
@@ -678,7 +678,7 @@ extern "C" int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nby
     if (ensure_layout(h)) return -1;
     if (K < 0 || K >= h->nK) return fail("bad panel index");
     *dev_ptr = (void*)panel_src(h, K);
-    *nbytes = (h->Npad - (int64_t)K * CK_NB) * CK_NB * 8;
+    *nbytes = ((h->Npad - (int64_t)K * CK_NB) * CK_NB + CK_PANEL_TAIL) * 8;   // rows + the diagonal blocks' inverses
     return 0;
 }
 
@@ -719,11 +719,13 @@ static void gemm_timed_collect(ck_handle* h, int slot) {
 static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
+    double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
     for (int q = 0; q < CK_NB / CK_IB; ++q) {
         double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
-        ck_launch_potrf64(st, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info);
+        double* linv = tail + (int64_t)q * CK_IB * CK_IB;
+        ck_launch_potrf64(st, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info, linv);
         const int64_t r1 = (int64_t)(q + 1) * CK_IB;
-        ck_launch_trsm64(st, P + r1 * CK_NB + q * CK_IB, CK_NB, R - r1, diag, CK_NB);
+        ck_launch_trsm64(st, P + r1 * CK_NB + q * CK_IB, CK_NB, R - r1, linv);
         const int64_t ncols = CK_NB - r1;
         if (ncols > 0) {
             const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
@@ -750,9 +752,9 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
 // forward substitution of the right-hand-side rows with the diagonal block of panel K
 static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
+    const double* tail = P + (h->Npad - (int64_t)K * CK_NB) * CK_NB;
     for (int q = 0; q < CK_NB / CK_IB; ++q) {
-        const double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
-        ck_launch_trsm64(st, X + q * CK_IB, CK_NB, h->mpad, diag, CK_NB);
+        ck_launch_trsm64(st, X + q * CK_IB, CK_NB, h->mpad, tail + (int64_t)q * CK_IB * CK_IB);
         const int64_t r1 = (int64_t)(q + 1) * CK_IB;
         const int64_t ncols = CK_NB - r1;
         if (ncols > 0)
@@ -1452,9 +1454,9 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     const int nK = (int)(Np / CK_NB);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     int64_t tot = 2 * al(3 * Np * 8) + al(Np * 8);
-    for (int K = h->rank; K < nK; K += h->world) tot += al((Np - (int64_t)K * CK_NB) * CK_NB * 8);
+    for (int K = h->rank; K < nK; K += h->world) tot += al(((Np - (int64_t)K * CK_NB) * CK_NB + CK_PANEL_TAIL) * 8);
     tot += 2 * al((int64_t)nK * sizeof(double*));   // d_sigptr, d_panelptr
-    if (h->world > 1) tot += 2 * al(Np * CK_NB * 8);
+    if (h->world > 1) tot += 2 * al((Np * CK_NB + CK_PANEL_TAIL) * 8);
     const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
     tot += al(mpad * Np * 8) + 2 * al(3 * mpad * 8) + 2 * al(2 * mpad * 8);
     *out = tot + 4096;

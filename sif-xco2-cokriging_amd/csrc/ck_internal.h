@@ -10,6 +10,9 @@
 #define CK_IB 64    // inner block (diagonal factor / row solves)
 #define CK_BM 256   // GEMM tile rows
 #define CK_AUX_ALIGN 256
+// every packed panel carries, behind its rows, the inverses of its eight 64 x 64 diagonal blocks
+// (k_potrf64 -> k_trsm64m); they travel with the panel in the multi-GPU broadcast
+#define CK_PANEL_TAIL ((CK_NB / CK_IB) * CK_IB * CK_IB)
 
 // ---- covariance assembly (ck_cov.hip) ---------------------------------------
 // per-site transform: degrees -> (lat_rad, lon_rad, cos lat) | (x, y, 0)
@@ -85,9 +88,10 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
                            int nJ, int64_t Npad);
 // In-place Cholesky of the 64 x 64 diagonal block at A (ld); info_dev gets global_index0 + j + 1 of
 // the first non-positive pivot (only if still 0).
-void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev);
+void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
+                       double* Linv);
 // X L^T = A in place for `nrows` rows of A (ld), 64 columns; L (64 x 64 lower, ldl).  nrows % 64 == 0.
-void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl);
+void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* Linv);
 // pred[p] = sum_c X[p][c] y[c];  err[p] = nan_to_num(sqrt(c0 - sum_c X[p][c]^2)); X rows live in
 // n_panels panels of width CK_NB at aux + K * mpad * CK_NB; y is row `zrow`.
 // c0 < 0: raw mode, pred[p] = X_p . y and err[p] = |X_p|^2 (leave-one-out).

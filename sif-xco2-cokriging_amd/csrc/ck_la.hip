@@ -941,7 +941,7 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 }
 
 // ---------------------------------------------------------------------------------------
-// 64 x 64 Cholesky of a diagonal block (one workgroup, register resident)
+// 64 x 64 Cholesky of a diagonal block AND its inverse (one workgroup, register resident)
 // ---------------------------------------------------------------------------------------
 // Thread (bi, bk) = (t >> 4, t & 15) keeps the 4 x 4 block rows 4bi.., cols 4bk.. in registers.
 // Right-looking on the UNSCALED columns: at step j the owners of column j publish it through a
@@ -949,9 +949,19 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 // its elements with j < k <= i.  The pivots a[j][j] are final once step j - 1 is done, so the
 // scaling L[i][j] = a[i][j] / sqrt(a[j][j]) is applied once at the end.  One barrier per step,
 // no LDS read-modify-write.
-__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info) {
+// Then the inverse, for the row solves against this block (k_trsm64m: a product with L^-T on the
+// matrix cores instead of a 64-step substitution per row): L goes to LDS transposed and the first
+// wave solves X L^T = I, lane r holding row r of X = L^-T, i.e. column r of L^-1, in registers
+// (right-looking, multipliers of a step contiguous, read as ds_read_b128 broadcasts).
+// (Carrying the inverse along inside the 64 factorisation steps -- the same row operations applied
+// to an identity -- was measured: 35 us against 23 us + this phase.)
+// Linv: 64 x 64 row-major, lower triangle, upper zero.
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info,
+                                                  double* __restrict__ Linv) {
     __shared__ double col[2][64];
     __shared__ double pv[64];
+    __shared__ __attribute__((aligned(16))) double Lt[64][66];   // Lt[c][i] = L[i][c]
+    __shared__ double rdiag[64];
     const int t = threadIdx.x, bi = t >> 4, bk = t & 15;
     const bool lower = bk <= bi;
     double a[4][4];
@@ -996,6 +1006,14 @@ __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld
         }
     }
     __syncthreads();
+    // D^-1/2 once per index (not a sqrt and a division per element)
+    double* rs = col[0];
+    if (t < 64) {
+        const double d = sqrt(pv[t]);
+        rs[t] = 1.0 / d;
+        rdiag[t] = 1.0 / d;           // 1 / L[t][t]
+    }
+    __syncthreads();
     if (lower) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1003,52 +1021,21 @@ __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld
             for (int c = 0; c < 4; ++c) {
                 const int i = 4 * bi + r, k = 4 * bk + c;
                 if (k <= i) {
-                    const double d = sqrt(pv[k]);
-                    A[(long)i * ld + k] = (k == i) ? d : a[r][c] / d;
+                    const double v = (k == i) ? sqrt(pv[k]) : a[r][c] * rs[k];
+                    A[(long)i * ld + k] = v;
+                    Lt[k][i] = v;
                 }
             }
     }
-}
-
-void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev) {
-    k_potrf64<<<dim3(1), dim3(256), 0, s>>>(A, ld, global_index0, info_dev);
-}
-
-// ---------------------------------------------------------------------------------------
-// X L^T = A  (64 columns, rows independent): one row per lane, L broadcast from LDS
-// ---------------------------------------------------------------------------------------
-// 256 threads = 256 rows per workgroup (the last one may be partial); every lane keeps its row in
-// registers and substitutes right-looking:  x[c] *= 1 / L[c][c];  x[c2] -= x[c] L[c2][c], c2 > c.
-// The factor sits in LDS TRANSPOSED (Lt[c][c2] = L[c2][c]) so the multipliers of one elimination
-// step are contiguous and come in pairs through ds_read_b128 broadcasts; the reciprocals of the
-// diagonal are prepared once per workgroup.  Rows go straight between global memory and
-// registers (each lane owns 512 contiguous bytes).
-// (Feeding L through scalar loads instead of LDS was tried and measured 2x slower.)
-__global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long ld, long nrows,
-                                                    const double* __restrict__ L, long ldl) {
-    __shared__ __attribute__((aligned(16))) double Lt[64][66];
-    __shared__ double rdiag[64];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        Lt[c][r] = L[r * ldl + c];
-    }
-    if (tid < 64) rdiag[tid] = 1.0 / L[tid * ldl + tid];
-    const long r = (long)blockIdx.x * 256 + tid;
-    const bool live = r < nrows;
-    double* row = A + (live ? r : 0) * ld;
+    __syncthreads();
+    if (t >= 64) return;
+    // X L^T = I, lane r = row r of X (entries below... x[c] for c < r stay 0: uniform code, no branches)
     double x[64];
 #pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        const d2_t v = *reinterpret_cast<const d2_t*>(row + c);
-        x[c] = v[0];
-        x[c + 1] = v[1];
-    }
-    __syncthreads();
+    for (int c = 0; c < 64; ++c) x[c] = (c == t) ? 1.0 : 0.0;
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         x[c] *= rdiag[c];
-        // multipliers L[c2][c] = Lt[c][c2]: odd leading element, then aligned pairs
         if (((c + 1) & 1) && c + 1 < 64) x[c + 1] -= x[c] * Lt[c][c + 1];
 #pragma unroll
         for (int c2 = (c + 2) & ~1; c2 < 64; c2 += 2) {
@@ -1057,20 +1044,55 @@ __global__ __launch_bounds__(256, 2) void k_trsm64(double* __restrict__ A, long 
             x[c2 + 1] -= x[c] * m[1];
         }
     }
-    if (live) {
+    // x[i] = (L^-T)[t][i] = Linv[i][t]: for fixed i the 64 lanes write 512 contiguous bytes
 #pragma unroll
-        for (int c = 0; c < 64; c += 2) {
-            d2_t v;
-            v[0] = x[c];
-            v[1] = x[c + 1];
-            *reinterpret_cast<d2_t*>(row + c) = v;
+    for (int i = 0; i < 64; ++i) Linv[i * 64 + t] = x[i];
+}
+
+void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
+                       double* Linv) {
+    k_potrf64<<<dim3(1), dim3(256), 0, s>>>(A, ld, global_index0, info_dev, Linv);
+}
+
+// ---------------------------------------------------------------------------------------
+// X L^T = A  (64 columns, rows independent) as  X = A Linv^T  on the matrix cores
+// ---------------------------------------------------------------------------------------
+// One workgroup = 64 rows, in place: the rows and Linv (k_potrf64) are staged in LDS through
+// coalesced 512-byte row segments, wave w takes rows 16 w .. 16 w + 15 and the four 16-column tiles
+// of X; Linv is lower triangular, so column tile jt needs k < 16 (jt + 1) only: 40 MFMA 16x16x4 per
+// wave.  (The first version kept one row per lane in registers and substituted through 64 steps of
+// LDS-broadcast multipliers, rows read as 512 contiguous bytes PER LANE: 27 us per launch.)
+__global__ __launch_bounds__(256, 2) void k_trsm64m(double* __restrict__ A, long ld, long nrows,
+                                                     const double* __restrict__ Linv) {
+    constexpr int PITCH = 66;   // doubles per LDS row
+    __shared__ __attribute__((aligned(16))) double As[64 * PITCH];
+    __shared__ __attribute__((aligned(16))) double Li[64 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long row0 = (long)blockIdx.x * 64;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        As[r * PITCH + c] = A[(row0 + r) * ld + c];
+        Li[r * PITCH + c] = Linv[idx];
+    }
+    __syncthreads();
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4 * (jt + 1); ++s) {
+            const double av = As[(16 * w + li) * PITCH + 4 * s + g];
+            const double bv = Li[(16 * jt + li) * PITCH + 4 * s + g];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(row0 + 16 * w + g + 4 * r) * ld + 16 * jt + li] = acc[r];
     }
 }
 
-void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* L, int64_t ldl) {
+void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* Linv) {
     if (nrows <= 0) return;
-    k_trsm64<<<dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s>>>(A, ld, nrows, L, ldl);
+    k_trsm64m<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(A, ld, nrows, Linv);   // nrows is a multiple of 64 (host)
 }
 
 // ---------------------------------------------------------------------------------------
