@@ -210,6 +210,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects the GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
  * "panel_group" (1..16, default 3) = panels per trailing update of ck_factor / ck_predict;
+ * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
+ * 32 GiB; the points are processed in batches that fit);
  * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
  * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,

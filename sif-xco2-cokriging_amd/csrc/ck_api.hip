@@ -127,6 +127,7 @@ struct ck_handle {
     // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
     int panel_group = 3;
+    int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
@@ -1183,26 +1184,52 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     std::vector<int> cnt(m);
     HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    // scratch slabs for neighbourhoods beyond the LDS limit
+    // Scratch slabs for neighbourhoods beyond the LDS limit.  The points are processed in consecutive
+    // batches whose slabs fit a budget (a quarter of the free device memory, at most 32 GiB), so that
+    // large radii over many points do not need sum_p k_p^2 doubles at once.
     const int kl = ck_local_lds_limit();
-    std::vector<long long> off(m, 0);
-    long long tot = 0;
+    std::vector<long long> off(m, 0), need(m, 0);
     int64_t kmx = 0, nempty = 0;
+    long long need_max = 0;
     for (int64_t p = 0; p < m; ++p) {
         const long long k = cnt[p];
         kmx = k > kmx ? k : kmx;
         if (k == 0) ++nempty;
         if (k > kl) {
-            off[p] = tot;
-            tot += (k + 2) * k + (k + 1) / 2 + 2;   // matrix + index list (ints), kept 16-byte aligned
-            tot = (tot + 1) & ~1LL;
+            need[p] = ((k + 2) * k + (k + 1) / 2 + 2 + 1) & ~1LL;   // matrix + index list (ints), kept 16-byte aligned
+            need_max = need[p] > need_max ? need[p] : need_max;
         }
     }
-    if (tot > 0) HIPCHK(hipMalloc((void**)&d_slab, (size_t)tot * 8));
+    size_t mem_free = 0, mem_total = 0;
+    HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+    long long budget = (long long)std::min<size_t>(mem_free / 4, (size_t)32 << 30) / 8;   // doubles
+    if (h->local_slab_mb > 0) budget = (long long)h->local_slab_mb * (1 << 20) / 8;      // option "local_slab_mb" (tests)
+    if (budget < need_max) budget = need_max;
+    if ((size_t)need_max * 8 > mem_free) return fail("ck_predict_local: a neighbourhood of " + std::to_string(kmx) + " sites does not fit the device memory");
+    std::vector<std::pair<int64_t, int64_t>> batches;   // [begin, end)
+    long long slab_doubles = 0;
+    {
+        int64_t b0 = 0;
+        long long acc = 0;
+        for (int64_t p = 0; p < m; ++p) {
+            if (acc + need[p] > budget && p > b0) {
+                batches.push_back({b0, p});
+                slab_doubles = acc > slab_doubles ? acc : slab_doubles;
+                b0 = p;
+                acc = 0;
+            }
+            off[p] = acc;
+            acc += need[p];
+        }
+        batches.push_back({b0, m});
+        slab_doubles = acc > slab_doubles ? acc : slab_doubles;
+    }
+    if (slab_doubles > 0) HIPCHK(hipMalloc((void**)&d_slab, (size_t)slab_doubles * 8));
     HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
-    ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, h->z,
-                          layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp);
+    for (const auto& bt : batches)
+        ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, bt.first, bt.second - bt.first,
+                              mp, h->s0, h->z, layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(pred, d_out, m * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1523,6 +1550,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
         h->lookahead = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "local_slab_mb")) {
+        if (value < 0) return fail("local_slab_mb must be >= 0");
+        h->local_slab_mb = value;
         return 0;
     }
     if (!strcmp(name, "panel_group")) {   // panels per trailing update (1 = after every panel)

@@ -128,7 +128,7 @@ void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double
 // slab_off[p]: offset (doubles) of point p's scratch slab ((k + 2) k doubles + k ints) when its
 // neighbourhood exceeds the LDS limit
 void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
-                           const double* pc, int64_t m, int64_t mpad, const double* sc, const double* z, CkLayout L,
-                           const int* counts, const long long* slab_off, double* slab, double c0var, double* pred,
-                           double* err);
+                           const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
+                           CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
+                           double* pred, double* err);
 int ck_local_lds_limit();

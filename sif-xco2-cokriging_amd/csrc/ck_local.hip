@@ -10,8 +10,11 @@
 //                    (forward substitution only: pred = v.y, var = c0 - v.v)
 // Empty neighbourhood -> (NaN, NaN) (:229-233); local Sigma not positive definite -> (NaN, NaN)
 // (:218-222).  Neighbours keep the reference's order: process 0 sites ascending, then process 1.
-// Systems with k <= 124 neighbours live in LDS; larger ones in a global scratch slab per point.
+// Systems with k <= 124 neighbours live in LDS (k_local_solve); larger ones in a global scratch slab per
+// point with a blocked factorisation (k_local_solve_big).
 #include "ck_internal.h"
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 #define LP_TPB 256
 #define LP_KL 124            // (124 + 2) * 124 doubles = 125 KB of LDS
@@ -59,14 +62,15 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
                                                          const int* __restrict__ counts,
                                                          const long long* __restrict__ slab_off,
                                                          double* __restrict__ slab, double c0var,
-                                                         double* __restrict__ pred, double* __restrict__ err) {
+                                                         double* __restrict__ pred, double* __restrict__ err,
+                                                         long p_base) {
     __shared__ double lS[(LP_KL + 2) * LP_KL];
     __shared__ int lidx[LP_KL];
     __shared__ int wsum[LP_TPB / 64];
     __shared__ int fail;
     __shared__ double red[2][LP_TPB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long p = blockIdx.x;
+    const long p = p_base + blockIdx.x;
     const int k = counts[p];
     if (k == 0) {   // src/point_prediction.py:229-233
         if (tid == 0) {
@@ -75,21 +79,13 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
         }
         return;
     }
+    if (k > LP_KL) return;   // larger systems: k_local_solve_big
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
     // storage: (k + 2) x k matrix (rows k, k + 1 carry c and z) and the neighbour index list
-    double* S;
-    int* idx;
-    long ld;
-    if (k <= LP_KL) {
-        S = lS;
-        idx = lidx;
-        ld = LP_KL;
-    } else {
-        S = slab + slab_off[p];
-        idx = reinterpret_cast<int*>(S + (long)(k + 2) * k);
-        ld = k;
-    }
+    double* S = lS;
+    int* idx = lidx;
+    const long ld = LP_KL;
     // ---- 1. neighbour list, in site order (block-wide ordered compaction) ----
     if (tid == 0) fail = 0;
     int base = 0;
@@ -183,19 +179,200 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Neighbourhoods beyond the LDS limit: blocked Cholesky of the local system in a global slab
+// ---------------------------------------------------------------------------------------
+// Same steps as k_local_solve (neighbour list in site order, local covariance with the c and z rows
+// riding along, forward substitution only).  The factorisation is blocked: LB_IB columns are
+// factored in place (unblocked, rank-1 updates confined to the column panel), then the trailing
+// matrix is updated ONCE with all of them -- 64 x 64 tiles, the two LB_IB-wide operand strips of
+// a tile staged (transposed) in LDS, a 4 x 4 register tile per thread.  The unblocked form makes
+// one pass over the trailing matrix per COLUMN: k / LB_IB times the memory traffic (it measured
+// 0.4 TFLOP/s at k = 1 359).
+#define LB_IB 32
+__global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __restrict__ blk, int metric, int i_pred,
+                                                             int cv, double max_dist,
+                                                             const double* __restrict__ pc, long mpad,
+                                                             const double* __restrict__ sc,
+                                                             const double* __restrict__ z, CkLayout L,
+                                                             const int* __restrict__ counts,
+                                                             const long long* __restrict__ slab_off,
+                                                             double* __restrict__ slab, double c0var,
+                                                             double* __restrict__ pred, double* __restrict__ err,
+                                                             long p_base) {
+    __shared__ __attribute__((aligned(16))) double At[LB_IB][64 + 4];   // At[c][r] = strip of the tile's rows
+    __shared__ __attribute__((aligned(16))) double Bt[LB_IB][64 + 4];   // Bt[c][r] = strip of the tile's columns
+    __shared__ int wsum[LP_TPB / 64];
+    __shared__ int fail;
+    __shared__ double red[2][LP_TPB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long p = p_base + blockIdx.x;
+    const int k = counts[p];
+    if (k <= LP_KL) return;   // k_local_solve (also the empty neighbourhoods)
+    const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
+    const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
+    double* S = slab + slab_off[p];   // (k + 2) x k, rows k and k + 1 carry c and z
+    int* idx = reinterpret_cast<int*>(S + (long)(k + 2) * k);
+    const long ld = k;
+    // ---- 1. neighbour list, in site order (block-wide ordered compaction) ----
+    if (tid == 0) fail = 0;
+    int base = 0;
+    for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {
+        const long g = g0 + tid;
+        const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
+        const unsigned long long bal = __ballot(f);
+        const int below = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < wv; ++w2) off += wsum[w2];
+        if (f) idx[off + below] = (int)g;
+        int tot = 0;
+        for (int w2 = 0; w2 < LP_TPB / 64; ++w2) tot += wsum[w2];
+        base += tot;
+        __syncthreads();
+    }
+    // ---- 2. local covariance (lower triangle), c row, z row ----
+    for (int a = 0; a < k; ++a) {   // row by row: coalesced writes, no sqrt to invert the triangular index
+        const long ga = idx[a];
+        const int pa = ga >= L.n0p;
+        const double a0 = s0[ga], a1 = s1[ga], a2 = s2[ga];
+        for (int b = tid; b <= a; b += LP_TPB) {
+            const long gb = idx[b];
+            const int pb = gb >= L.n0p;
+            const double d = lp_dist(metric, a0, a1, a2, s0[gb], s1[gb], s2[gb]);
+            S[(long)a * ld + b] = ck_cov_entry(blk[pa + pb], d, pa == pb);
+        }
+    }
+    for (int a = tid; a < k; a += LP_TPB) {
+        const long ga = idx[a];
+        const int pa = ga >= L.n0p;
+        const double d = lp_dist(metric, p0, p1, p2, s0[ga], s1[ga], s2[ga]);
+        S[(long)k * ld + a] = ck_cov_entry(blk[i_pred + pa], d, pa == i_pred);   // point_prediction.py:115-125
+        S[(long)(k + 1) * ld + a] = z[ga];
+    }
+    __syncthreads();
+    // ---- 3. blocked Cholesky; rows k, k + 1 ride along (forward substitution) ----
+    const int ty = tid >> 4, tx = tid & 15;
+    bool bad = false;
+    for (int jb = 0; jb < k && !bad; jb += LB_IB) {
+        const int nbc = (k - jb < LB_IB) ? (k - jb) : LB_IB;
+        const int jend = jb + nbc;
+        // 3a. the column panel jb .. jend - 1, all rows below
+        for (int j = jb; j < jend; ++j) {
+            const double piv = S[(long)j * ld + j];
+            if (!(piv > 0.0)) {   // uniform: every thread reads the same pivot
+                if (tid == 0) fail = 1;
+                bad = true;
+                break;
+            }
+            const double rd = 1.0 / sqrt(piv);
+            __syncthreads();
+            for (int a = j + 1 + tid; a < k + 2; a += LP_TPB) S[(long)a * ld + j] *= rd;
+            if (tid == 0) S[(long)j * ld + j] = sqrt(piv);
+            __syncthreads();
+            const int nbp = jend - 1 - j;        // panel columns b = j + 1 .. jend - 1
+            const int na = k + 1 - j;            // rows a = j + 1 .. k + 1
+            if (nbp > 0) {
+                const long tot = (long)na * nbp;
+                for (long e = tid; e < tot; e += LP_TPB) {
+                    const int a = j + 1 + (int)(e / nbp), b = j + 1 + (int)(e % nbp);
+                    if (b <= a) S[(long)a * ld + b] -= S[(long)a * ld + j] * S[(long)b * ld + j];
+                }
+            }
+            __syncthreads();
+        }
+        if (bad) break;
+        // 3b. trailing update  S[a][b] -= sum_c S[a][jb + c] S[b][jb + c],  a in [jend, k + 2), b in [jend, min(a, k - 1)]
+        const int nrow = k + 2 - jend, ncol = k - jend;
+        const int tr = (nrow + 63) / 64, tc = (ncol + 63) / 64;
+        for (int ta = 0; ta < tr; ++ta) {
+            for (int tb = 0; tb < tc && tb <= ta; ++tb) {
+                for (int e = tid; e < 64 * LB_IB; e += LP_TPB) {
+                    const int r = e / LB_IB, c = e % LB_IB;            // consecutive threads: consecutive columns of one row
+                    const int a = jend + ta * 64 + r, b = jend + tb * 64 + r;
+                    At[c][r] = (a < k + 2 && c < nbc) ? S[(long)a * ld + jb + c] : 0.0;
+                    Bt[c][r] = (b < k && c < nbc) ? S[(long)b * ld + jb + c] : 0.0;
+                }
+                __syncthreads();
+                double acc[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) acc[i][j2] = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < LB_IB; ++c) {
+                    const d2_t a01 = *reinterpret_cast<const d2_t*>(&At[c][4 * ty]), a23 = *reinterpret_cast<const d2_t*>(&At[c][4 * ty + 2]);
+                    const d2_t b01 = *reinterpret_cast<const d2_t*>(&Bt[c][4 * tx]), b23 = *reinterpret_cast<const d2_t*>(&Bt[c][4 * tx + 2]);
+                    const double av[4] = {a01[0], a01[1], a23[0], a23[1]}, bv[4] = {b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) acc[i][j2] = fma(av[i], bv[j2], acc[i][j2]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int a = jend + ta * 64 + 4 * ty + i;
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        const int b = jend + tb * 64 + 4 * tx + j2;
+                        if (a < k + 2 && b < k && b <= a) S[(long)a * ld + b] -= acc[i][j2];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (fail) {   // src/point_prediction.py:218-222
+        if (tid == 0) {
+            pred[p] = NAN;
+            err[p] = NAN;
+        }
+        return;
+    }
+    // ---- 4. pred = v . y, var = c0 - v . v ----
+    double s1v = 0.0, s2v = 0.0;
+    for (int a = tid; a < k; a += LP_TPB) {
+        const double v = S[(long)k * ld + a], y = S[(long)(k + 1) * ld + a];
+        s1v += v * y;
+        s2v += v * v;
+    }
+    red[0][tid] = s1v;
+    red[1][tid] = s2v;
+    __syncthreads();
+    for (int s = LP_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pred[p] = red[0][0];
+        const double sd = sqrt(c0var - red[1][0]);
+        err[p] = (sd == sd) ? fmax(sd, 0.0) : 0.0;   // np.nanmax([std, 0.0]), point_prediction.py:217
+    }
+}
+
 void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double max_dist, const double* pc,
                            int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts) {
     if (m <= 0) return;
     k_local_count<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(metric, i_pred, cv, max_dist, pc, mpad, sc, L, counts);
 }
 
+// points [p_base, p_base + m): slab_off is relative to `slab` within this batch (ck_predict_local)
 void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
-                           const double* pc, int64_t m, int64_t mpad, const double* sc, const double* z, CkLayout L,
-                           const int* counts, const long long* slab_off, double* slab, double c0var, double* pred,
-                           double* err) {
+                           const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
+                           CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
+                           double* pred, double* err) {
     if (m <= 0) return;
     k_local_solve<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                             counts, slab_off, slab, c0var, pred, err);
+                                                             counts, slab_off, slab, c0var, pred, err, p_base);
+    if (slab)   // some neighbourhood is larger than the LDS limit
+        k_local_solve_big<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z,
+                                                                     L, counts, slab_off, slab, c0var, pred, err,
+                                                                     p_base);
 }
 
 int ck_local_lds_limit() { return LP_KL; }

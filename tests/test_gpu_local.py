@@ -66,6 +66,46 @@ def test_local_large_neighbourhood_matches_joint():
     assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-9
 
 
+def test_local_large_neighbourhood_not_positive_definite():
+    """The blocked large-neighbourhood path (k = 520 > the LDS limit) on an indefinite model: every
+    local system fails like the joint one does -> (NaN, NaN) per point (src/point_prediction.py:218-222)."""
+    from sif_xco2_cokriging_amd import native
+    g = load_golden("joint_not_pd")
+    pv = g["params"]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(0)
+    h.set_data(0, g["coords0"], np.zeros(260))
+    h.set_data(1, g["coords1"], np.zeros(260))
+    pc = g["coords0"][:7] + 0.013
+    pred, err, info = h.predict_local(0, pc, max_dist=1e9)
+    assert info["k_max"] == 520 and info["n_not_pd"] == 7
+    assert np.all(np.isnan(pred)) and np.all(np.isnan(err))
+
+
+def test_local_mid_sized_neighbourhoods_vs_oracle():
+    """Neighbourhoods of a few hundred sites (blocked path, sizes that are not multiples of the 32-column
+    block or the 64-row tile) against the oracle's per-point solves."""
+    from sif_xco2_cokriging_amd import native, synth
+    from oracle import cokrige_oracle as orc
+    pb = synth.conus_problem(1500, seed=9)
+    pv = pb["params"]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(0)
+    for k in range(2):
+        h.set_data(k, pb["coords"][k], pb["values"][k])
+    pc = pb["pcoords"][::173][:40]
+    pred, err, info = h.predict_local(0, pc, max_dist=900.0)
+    assert info["k_max"] > 300
+    h.set_option("local_slab_mb", 3)   # force several point batches through one small scratch slab
+    pred_b, err_b, _ = h.predict_local(0, pc, max_dist=900.0)
+    assert np.array_equal(pred, pred_b) and np.array_equal(err, err_b)
+    rp, re = orc.local_predict(orc.Params.from_flat(pv), pb["coords"], pb["values"], pc, 0, 0, 900.0)[:2]
+    np.testing.assert_allclose(pred, rp, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(err ** 2, re ** 2, rtol=1e-8, atol=1e-10)
+
+
 def test_predictor_call_signature_and_warnings():
     import pandas as pd
     P, g = _predictor("A")
