@@ -127,6 +127,7 @@ struct ck_handle {
     // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
     int panel_group = 3;
+    int gemm_variant = CK_GEMM_DEFAULT;   // option "gemm_variant"
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
@@ -731,7 +732,7 @@ static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
         if (ncols > 0) {
             const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
             ck_launch_gemm_nt(st, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
-                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
+                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0, h->gemm_variant);
         }
     }
 }
@@ -743,10 +744,10 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     if (J0 > Jhi) return;
     const int nJ = (Jhi - J0) / h->world + 1;
     if (timed) gemm_timed_begin(h, st);
-    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
-        ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad);
+    if (h->gemm_variant == 7 || h->gemm_variant == 8)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
+        ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad, h->gemm_variant);
     else
-        ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad);
+        ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad, h->gemm_variant);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -760,7 +761,7 @@ static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
         const int64_t ncols = CK_NB - r1;
         if (ncols > 0)
             ck_launch_gemm_nt(st, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB, h->mpad,
-                              ncols, CK_IB, 0, 0, 1, 0, 0, 0);
+                              ncols, CK_IB, 0, 0, 1, 0, 0, 0, h->gemm_variant);
     }
 }
 
@@ -770,12 +771,12 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     if (timed) gemm_timed_begin(h, st);
-    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8)
-        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ);
+    if (h->gemm_variant == 7 || h->gemm_variant == 8)
+        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, h->gemm_variant);
     else
         ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
                           P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
-                          h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB);
+                          h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB, h->gemm_variant);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -869,14 +870,14 @@ static int factor_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad);
+                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad, h->gemm_variant);
                     gemm_timed_end(h);
                 }
                 panel_factor_on(h, K0 + g, h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad);
+                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad, h->gemm_variant);
                 gemm_timed_end(h);
             }
         }
@@ -913,14 +914,14 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1);
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, h->gemm_variant);
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc);
+                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->gemm_variant);
                 gemm_timed_end(h);
             }
         }
@@ -1544,8 +1545,8 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->time_gemm = value != 0;
         return 0;
     }
-    if (!strcmp(name, "gemm_variant")) {   // process-wide A/B switch of the GEMM tile structure
-        g_ck_gemm_variant = (int)value;
+    if (!strcmp(name, "gemm_variant")) {   // A/B switch of the GEMM tile structure (this handle)
+        h->gemm_variant = (int)value;
         return 0;
     }
     if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
@@ -1606,7 +1607,7 @@ extern "C" int ck_dev_gemm_nt(ck_handle* h, double* C, int64_t ldc, const double
                               int64_t ldb, int64_t M, int64_t N, int64_t K, int lower) {
     CHKH(h);
     if (M % CK_BM || N % 64 || K % 16) return fail("ck_dev_gemm_nt: M % 256, N % 64, K % 16 must be 0");
-    ck_launch_gemm_nt(h->stream, C, ldc, A, lda, B, ldb, M, N, K, lower, 0, 1, 0, 0, 0);
+    ck_launch_gemm_nt(h->stream, C, ldc, A, lda, B, ldb, M, N, K, lower, 0, 1, 0, 0, 0, h->gemm_variant);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -804,47 +804,47 @@ __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) vo
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 (the
 // block-column-cyclic stride of a multi-process run) is served by the LDS-DMA form only
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad) {
+                          int Jstep, int nJ, int64_t Npad, int variant) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
-    if (g_ck_gemm_variant == 6) {
+    if (variant == 6) {
         const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 64)), (unsigned)nJ);
         k_syrk_group<4, 64><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
         return;
     }
-    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8) {
+    if (variant == 7 || variant == 8) {
         const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-        if (g_ck_gemm_variant == 7)
+        if (variant == 7)
             k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
         else
             k_syrk_group_d<4><<<grid, dim3(256), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
         return;
     }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (g_ck_gemm_variant == 4)
+    if (variant == 4)
         k_syrk_group<4, 128><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
     else
         k_syrk_group<8, 128><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
 }
 
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ) {
+                         int nJ, int variant) {
     if (nJ <= 0 || np <= 0 || mpad <= 0) return;
-    if (g_ck_gemm_variant == 6) {
+    if (variant == 6) {
         const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 64)), (unsigned)nJ);
         k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         return;
     }
-    if (g_ck_gemm_variant == 7 || g_ck_gemm_variant == 8) {
+    if (variant == 7 || variant == 8) {
         const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-        if (g_ck_gemm_variant == 7)
+        if (variant == 7)
             k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         else
             k_aux_group_d<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
         return;
     }
     const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (g_ck_gemm_variant == 4)
+    if (variant == 4)
         k_aux_group<4, 128><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
     else
         k_aux_group<8, 128><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
@@ -888,16 +888,17 @@ __global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restric
     gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
 }
 
-// 7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default); 5: the same staged
-// through registers; 4: 4 waves of 64x64 through registers; 8: 4 waves of 64x64, LDS-DMA; 6: 128x64 tiles, three
-// workgroups per CU; 0: one 256x128 workgroup per CU
-int g_ck_gemm_variant = 7;
+// Tile structures (handle option "gemm_variant", A/B tests; CK_GEMM_DEFAULT in ck_internal.h):
+//   7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default)
+//   5: the same staged through registers      4: 4 waves of 64x64 through registers
+//   8: 4 waves of 64x64, LDS-DMA              6: 128x64 tiles, three workgroups per CU
+//   0: one 256x128 workgroup per CU
 
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
-                       int64_t sC, int64_t sA, int64_t sB) {
+                       int64_t sC, int64_t sA, int64_t sB, int variant) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
-    const int v = g_ck_gemm_variant;
+    const int v = variant;
     if ((v == 5 || v == 6 || v == 7 || v == 8) && N % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
@@ -923,16 +924,16 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 }
 
 void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
-                           int nJ, int64_t Npad) {
+                           int nJ, int64_t Npad, int variant) {
     if (nJ <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
-    if (g_ck_gemm_variant >= 5 && g_ck_gemm_variant <= 8) {
+    if (variant >= 5 && variant <= 8) {
         k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
         return;
     }
-    if (g_ck_gemm_variant == 4) {
+    if (variant == 4) {
         k_syrk_panels_s<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(256), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
                                                                                       Npad);
         return;

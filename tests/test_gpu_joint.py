@@ -131,7 +131,6 @@ def test_gemm_nt_mfma(native, variant):
                         np.testing.assert_allclose(got[blk], ref[blk], rtol=1e-12, atol=1e-11)
         else:
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
-    h.set_option("gemm_variant", 7)
 
 
 def _assembled(native, params, coords, values, metric, exact=False, site_order=None):

@@ -66,7 +66,6 @@ def test_panel_groups_and_tile_variants(group, variant):
             op, oe = orc.joint_predict(p, pb["coords"], pb["values"], pb["coords"][0][ix], 0, pb["metric"], cv_ix=ix)
             assert abs(cp[ix] - op[0]) < 1e-8 * max(1.0, abs(op[0])) and abs(ce[ix] ** 2 - oe[0] ** 2) < 1e-9
     finally:
-        h.set_option("gemm_variant", 7)   # process-wide switch, back to the default
         h.close()
 
 
