@@ -347,3 +347,45 @@ def test_notebook_flow_end_to_end(native):
     assert np.allclose(err[-3:], [0.6993, 0.7249, 0.754], atol=6e-4)
     g = load_golden("kat_simulation_experiment")
     assert rel(pred, g["pred"]) < 1e-5
+
+
+@pytest.mark.parametrize("metric", [HAV, EUC])
+def test_table_path_across_the_parameter_box(native, metric):
+    """The tabulated assembly against the per-entry evaluator over the reference's whole parameter box
+    (src/model.py:122-129: nu in [0.2, 3.5], len_scale in [100, 2000] km, nugget in [0, 0.2]) including its
+    corners, on both metrics: wherever a block's table passed its gate the entries agree to the gate's
+    measure, and a table that fails the gate must have handed the block to the exact kernel."""
+    rng = np.random.default_rng(77)
+    n0, n1 = 190, 170
+    if metric == HAV:
+        c0 = np.column_stack([rng.uniform(25, 50, n0), rng.uniform(-120, -70, n0)])
+        c1 = np.column_stack([rng.uniform(25, 50, n1), rng.uniform(-120, -70, n1)])
+        ls_lo, ls_hi = 100.0, 2000.0
+    else:
+        c0, c1 = rng.random((n0, 2)), rng.random((n1, 2))
+        ls_lo, ls_hi = 0.02, 1.5
+    c1[:40] = c0[:40]                                   # co-located sites
+    z = [np.zeros(n0), np.zeros(n1)]
+    corners = [(0.2, 0.2, 0.2), (3.5, 3.5, 3.5), (0.2, 1.85, 3.5), (0.5, 1.5, 2.5)]
+    cases = []
+    for nu in corners:
+        for ls in ((ls_lo,) * 3, (ls_hi,) * 3, (ls_lo, 0.5 * (ls_lo + ls_hi), ls_hi)):
+            cases.append([1.3, 0.6, *nu, *ls, 0.0, 0.2, 0.35])
+    for _ in range(6):
+        cases.append([rng.uniform(0.4, 3.5), rng.uniform(0.4, 3.5), *rng.uniform(0.2, 3.5, 3),
+                      *rng.uniform(ls_lo, ls_hi, 3), *rng.uniform(0.0, 0.2, 2), rng.uniform(-0.9, 0.9)])
+    for pv in cases:
+        pv = np.array(pv, dtype=float)
+        low = {}
+        for exact in (0, 1):
+            h, _ = _assembled(native, pv, [c0, c1], z, metric, exact=bool(exact), site_order=0)
+            low[exact] = h.debug_get_lower(n0 + n1)
+            if not exact:
+                info = [h.table_info(b) for b in range(3)]
+            h.close()
+        scale = np.max(np.abs(np.diag(low[1])))
+        if all(t["enabled"] for t in info):
+            assert max(t["max_rel_err"] for t in info) < 2e-13
+            np.testing.assert_allclose(low[0], low[1], rtol=5e-13, atol=5e-19 * scale, err_msg=str(pv))
+        else:   # a gated-out table: the whole assembly went through the exact kernel
+            assert np.array_equal(low[0], low[1]), pv
