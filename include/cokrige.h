@@ -165,6 +165,9 @@ int ck_vario_begin(ck_handle* h, const double* coords_i_host, const double* resi
 /* Pass 1: lo = smallest positive and hi = largest pair distance among pairs with d <= max_dist
  * (src/fields.py:212, 394-395); n_positive = 0 if there is no such pair (lo, hi = NaN). */
 int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64_t* n_positive);
+/* With ck_set_partition(rank, world), world > 1, both passes visit only this rank's share of the pair
+ * tiles (tile t belongs to rank t mod world): the host combines the ranks' results -- MIN of lo / MAX of hi
+ * over the ranks that found a pair, SUM of the per-bin sums and counts (distributed.DistributedVariogram). */
 /* Pass 2: per-bin sum of cloud values and pair count for bins (e_b, e_b+1], first bin [0, e_1]
  * (pd.cut(include_lowest=True), :214-222); edges[0] must be 0; at most 36 bins.
  * cloud = 0.5 (a - b)^2, or a * b when covariogram != 0 (:378-386). */

@@ -1326,7 +1326,7 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     if (!h->vg_iu) return fail("ck_vario_begin has not been called");
     const double rcap = vario_r_of_dist(h->metric, max_dist);
     ck_launch_vario_extent(h->stream, h->vg_grid, h->metric, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj,
-                           rcap, h->vg_part);
+                           rcap, h->vg_part, h->rank, h->world);
     HIPCHK(hipGetLastError());
     std::vector<CkVarioExt> part(h->vg_grid);
     HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost,
@@ -1396,7 +1396,7 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     ck_launch_vario_bin(h->stream, h->vg_grid, h->metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv,
                         h->vg_ni, h->vg_ju, h->vg_jv, h->vg_nj, rcap, nb, d_thr, h->vg_lut, 1.0 / cell, h->vg_psum,
-                        h->vg_pcnt, d_sums, d_cnt);
+                        h->vg_pcnt, d_sums, d_cnt, h->rank, h->world);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     long long cnt[CK_VG_MAXBINS];

@@ -71,14 +71,15 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
                                                           const double* __restrict__ ju0,
                                                           const double* __restrict__ ju1,
                                                           const double* __restrict__ ju2, long nj, double rcap,
-                                                          VarioPartialExt* __restrict__ part) {
+                                                          VarioPartialExt* __restrict__ part, int rank, int world) {
     __shared__ double red_r[VG_TPB];
     __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
     const int tid = threadIdx.x;
     const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     double rmin = 1e300, rmax = -1.0;
     long long imin = -1, jmin = -1, imax = -1, jmax = -1;
-    for (long t = blockIdx.x; t < nI * nJ; t += gridDim.x) {
+    // tile list sharded over processes (ck_set_partition): this one takes the tiles t = rank (mod world)
+    for (long t = (long)blockIdx.x * world + rank; t < nI * nJ; t += (long)gridDim.x * world) {
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
                                                        int nb, const double* __restrict__ thr,
                                                        const unsigned char* __restrict__ lut, double inv_cell,
                                                        double* __restrict__ part_sum,
-                                                       unsigned long long* __restrict__ part_cnt) {
+                                                       unsigned long long* __restrict__ part_cnt, int rank, int world) {
     __shared__ double hsum[VG_MAXBINS + 1][VG_TPB];        // + 1: the trash row of pairs that are not retained
     __shared__ unsigned int hcnt[VG_MAXBINS + 1][VG_TPB];
     __shared__ double sthr[VG_MAXBINS + 2];
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
     }
     const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     // per-lane 64-bit count spill: hcnt is 32-bit, a lane sees at most nJ * VG_JCHUNK pairs per I block
-    for (long t = blockIdx.x; t < nI * nJ; t += gridDim.x) {
+    // tile list sharded over processes (ck_set_partition): this one takes the tiles t = rank (mod world)
+    for (long t = (long)blockIdx.x * world + rank; t < nI * nJ; t += (long)gridDim.x * world) {
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
@@ -288,17 +290,17 @@ int ck_vario_grid(int64_t ni, int64_t nj) {
 }
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
-                            const double* ju, int64_t nj, double rcap, void* part) {
+                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world) {
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj,
-                                                       ju + 2 * nj, nj, rcap, (VarioPartialExt*)part);
+                                                       ju + 2 * nj, nj, rcap, (VarioPartialExt*)part, rank, world);
 }
 
 void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
                          const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
                          int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
-                         unsigned long long* part_cnt, double* sums, long long* counts) {
+                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world) {
     k_vario_bin<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, covariogram, iu, iu + ni, iu + 2 * ni, iv, ni, ju,
                                                     ju + nj, ju + 2 * nj, jv, nj, rcap, nb, thr, lut, inv_cell,
-                                                    part_sum, part_cnt);
+                                                    part_sum, part_cnt, rank, world);
     k_vario_final<<<dim3(1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, sums, counts);
 }

@@ -18,6 +18,13 @@ Partition (include/cokrige.h, "step-wise form"):
 
 The torch tensors are plumbing: device memory (one uint8 arena the library carves its panels
 from), the stream, and the collective.  All arithmetic is in the HIP library.
+
+The two other paths of SURVEY.md section 8(e) shard without any exchange inside the computation:
+  * DistributedVariogram -- the pair tiles of the lag-binning kernels are dealt out round-robin
+    (tile t to rank t mod world); the ranks' extreme distances and per-bin sums / counts are
+    combined by one MIN/MAX and one SUM all-reduce;
+  * DistributedLocal -- the prediction points of the local-neighbourhood predictor are split into
+    contiguous shards (the observations are replicated), results gathered.
 """
 from __future__ import annotations
 
@@ -135,3 +142,84 @@ class DistributedJoint:
             from numpy.linalg import LinAlgError
             raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
         return pred, err
+
+
+def _to_dev(x, device):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64).to(device if device is not None else "cpu")
+
+
+class DistributedVariogram:
+    """Empirical (cross-)variogram with the pair tiles sharded over ranks (src/fields.py:192-232).
+    Every rank passes the SAME coordinates / values and receives the same result."""
+
+    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None):
+        self.h, self.rank, self.world = handle, int(rank), int(world)
+        self.dist, self.device, self.group = dist_module, device, group
+        handle.set_partition(self.rank, self.world)
+
+    def variogram_arrays(self, coords_i, values_i, coords_j, values_j, same, max_dist, n_bins, covariogram=False):
+        """(centers, edges, means, counts) -- as variogram.variogram_arrays on one device."""
+        from .variogram import construct_bins
+        h, dist = self.h, self.dist
+        vi = np.asarray(values_i, dtype=np.float64)
+        ri = vi - vi.mean()                       # src/fields.py:380
+        if same:
+            h.vario_begin(coords_i, ri)
+        else:
+            vj = np.asarray(values_j, dtype=np.float64)
+            h.vario_begin(coords_i, ri, coords_j, vj - vj.mean())
+        try:
+            lo, hi, npos = h.vario_extent(max_dist)
+            ext = np.array([lo if npos else np.inf, -(hi if npos else -np.inf), -float(bool(npos))])
+            if self.world > 1:                    # one MIN all-reduce: min lo, max hi, "anybody found a pair"
+                t = _to_dev(ext, self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+                ext = t.cpu().numpy()
+            if ext[2] == 0.0:
+                raise ValueError("no pair of distinct sites within max_dist")
+            lo, hi = float(ext[0]), float(-ext[1])
+            centers, edges = construct_bins(lo, hi, n_bins)
+            if len(edges) != n_bins + 1:
+                raise ValueError("Bin labels must be one fewer than the number of bin edges")
+            sums, counts = h.vario_bin(max_dist, edges, covariogram)
+            if self.world > 1:
+                import torch
+                ts = _to_dev(sums, self.device)
+                tc = torch.as_tensor(np.ascontiguousarray(counts), dtype=torch.int64).to(self.device if self.device is not None else "cpu")
+                dist.all_reduce(ts, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(tc, op=dist.ReduceOp.SUM, group=self.group)
+                sums, counts = ts.cpu().numpy(), tc.cpu().numpy()
+        finally:
+            h.vario_end()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            means = sums / counts
+        return centers, edges, means, counts
+
+
+class DistributedLocal:
+    """Local-neighbourhood predictor with the prediction points sharded over ranks
+    (src/point_prediction.py:45-96 uses Pool.starmap over partitions of the points)."""
+
+    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None):
+        self.h, self.rank, self.world = handle, int(rank), int(world)
+        self.dist, self.device, self.group = dist_module, device, group
+
+    def predict(self, i: int, pcoords, max_dist: float = 1e3, cv: bool = False):
+        import torch
+        pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
+        m = pc.shape[0]
+        chunk = -(-m // self.world)
+        lo = min(self.rank * chunk, m)
+        hi = min(lo + chunk, m)
+        pred_l, err_l, _ = self.h.predict_local(i, pc[lo:hi], max_dist, cv) if hi > lo else (np.empty(0), np.empty(0), None)
+        if self.world == 1:
+            return pred_l, err_l
+        dev = self.device if self.device is not None else "cpu"
+        buf = torch.full((2 * chunk,), float("nan"), dtype=torch.float64, device=dev)
+        buf[:hi - lo] = torch.from_numpy(np.ascontiguousarray(pred_l)).to(dev)
+        buf[chunk:chunk + hi - lo] = torch.from_numpy(np.ascontiguousarray(err_l)).to(dev)
+        allb = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(allb, buf, group=self.group)
+        allb = [b.cpu().numpy() for b in allb]
+        return (np.concatenate([b[:chunk] for b in allb])[:m], np.concatenate([b[chunk:] for b in allb])[:m])

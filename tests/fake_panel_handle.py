@@ -108,3 +108,53 @@ class FakePanelHandle:
 
     def factor_info(self):
         return self.info
+
+
+class FakeVarioHandle:
+    """TEST-ONLY stand-in for the variogram part of native.Handle (ck_vario_*), sharded like the device
+    kernels: with set_partition(rank, world) the two passes see only this rank's share of the pairs (here:
+    the rows i = rank mod world; the device deals out 256 x 1024 pair tiles).  Distances and cloud values
+    follow the oracle."""
+
+    def __init__(self, metric):
+        self.metric, self.rank, self.world = metric, 0, 1
+
+    def set_partition(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def vario_begin(self, coords_i, resid_i, coords_j=None, resid_j=None):
+        self.same = coords_j is None
+        ci, ri = np.asarray(coords_i, float), np.asarray(resid_i, float)
+        cj, rj = (ci, ri) if self.same else (np.asarray(coords_j, float), np.asarray(resid_j, float))
+        rows = np.arange(self.rank, len(ci), self.world)
+        d = orc.distance_matrix(ci[rows], cj, self.metric)
+        a, b = ri[rows], rj
+        self._semi = 0.5 * np.subtract.outer(a, b) ** 2
+        self._prod = np.multiply.outer(a, b)
+        mask = np.ones_like(d, dtype=bool)
+        if self.same:
+            mask = np.arange(len(cj))[None, :] > rows[:, None]      # strict upper triangle
+        self._d, self._mask = d, mask
+
+    def vario_extent(self, max_dist):
+        keep = self._mask & (self._d <= max_dist)
+        d = self._d[keep]
+        pos = d[d > 0]
+        if pos.size == 0:
+            return float("nan"), float("nan"), 0
+        return float(pos.min()), float(d.max()), 1
+
+    def vario_bin(self, max_dist, edges, covariogram=False):
+        keep = self._mask & (self._d <= max_dist)
+        d = self._d[keep]
+        cloud = (self._prod if covariogram else self._semi)[keep]
+        ids = np.searchsorted(edges, d, side="left")
+        ids[d == edges[0]] = 1
+        ok = (ids >= 1) & (ids <= len(edges) - 1)
+        nb = len(edges) - 1
+        counts = np.bincount(ids[ok] - 1, minlength=nb).astype(np.int64)
+        sums = np.bincount(ids[ok] - 1, weights=cloud[ok], minlength=nb)
+        return sums, counts
+
+    def vario_end(self):
+        self._d = self._mask = self._semi = self._prod = None

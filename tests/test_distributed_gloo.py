@@ -37,6 +37,16 @@ def _worker(rank, world, port, case, q):
             r = DistributedJoint(h, rank, world, dist_module=dist, lookahead=(case == "solve")).prepare(len(g["pcoords_A"]))
             pred, err = r.predict(1, g["pcoords_A"])
             q.put((rank, "ok", pred, err))
+        elif case == "vario":
+            from sif_xco2_cokriging_amd.distributed import DistributedVariogram
+            from tests.fake_panel_handle import FakeVarioHandle
+            g = load_golden("variogram")
+            dv = DistributedVariogram(FakeVarioHandle(0), rank, world, dist_module=dist)
+            out = []
+            for (ci, vi, cj, vj, same) in ((g["coords0"], g["values0"], None, None, True),
+                                           (g["coords0"], g["values0"], g["coords1"], g["values1"], False)):
+                out.append(dv.variogram_arrays(ci, vi, cj, vj, same, 1500.0, 30))
+            q.put((rank, "ok", out, None))
         else:
             g = load_golden("joint_not_pd")
             h = FakePanelHandle(g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], 0)
@@ -101,3 +111,18 @@ def test_single_rank_fake_matches_oracle():
     h = FakePanelHandle(g["params_R"], [g["coords0_R"], g["coords1_R"]], [g["values0_R"], g["values1_R"]], 0)
     pred, err = DistributedJoint(h, 0, 1).prepare(120).predict(0, g["pcoords_R"])
     assert np.max(np.abs(pred - g["pred_R_0"])) / np.max(np.abs(g["pred_R_0"])) < 1e-9
+
+
+def test_sharded_variogram_two_and_three_ranks():
+    """DistributedVariogram: pair tiles dealt out over the ranks, MIN/MAX all-reduce of the extreme
+    distances, SUM all-reduce of the per-bin sums and counts -- against the reference's fixture."""
+    g = load_golden("variogram")
+    for world in (2, 3):
+        out = _run(world, "vario")
+        for rank, status, res, _ in out:
+            assert status == "ok"
+            for (i, j), (centers, edges, means, counts) in zip(((0, 0), (0, 1)), res):
+                key = f"semi_1500_30_{i}{j}"
+                assert np.array_equal(counts, g[key + "_counts"])
+                np.testing.assert_allclose(centers, g[key + "_centers"], rtol=1e-12)
+                np.testing.assert_allclose(means, g[key + "_means"], rtol=1e-11, atol=1e-14)

@@ -128,3 +128,79 @@ def test_world1_driver_with_arena_matches_direct():
     p2, e2 = h2.predict(1, g["pcoords_R"])
     assert np.array_equal(p1, p2) and np.array_equal(e1, e2)
     assert np.max(np.abs(p1 - g["pred_R_1"])) / np.max(np.abs(g["pred_R_1"])) < 1e-9
+
+
+def _worker_vario_local(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sif_xco2_cokriging_amd import native
+        from sif_xco2_cokriging_amd.distributed import DistributedLocal, DistributedVariogram
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        g = load_golden("variogram")
+        h = native.Handle(0)
+        h.set_metric(0)
+        dv = DistributedVariogram(h, rank, world, dist_module=dist, device=dev)
+        vres = []
+        for (ci, vi, cj, vj, same) in ((g["coords0"], g["values0"], None, None, True),
+                                       (g["coords0"], g["values0"], g["coords1"], g["values1"], False)):
+            vres.append(dv.variogram_arrays(ci, vi, cj, vj, same, 1500.0, 30))
+        h.close()
+        # local predictor, points sharded
+        s = load_golden("joint_solve")
+        pv = s["params_A"]
+        h2 = native.Handle(0)
+        h2.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h2.set_metric(0)
+        h2.set_data(0, s["coords0_A"], s["values0_A"])
+        h2.set_data(1, s["coords1_A"], s["values1_A"])
+        pred, err = DistributedLocal(h2, rank, world, dist_module=dist, device=dev).predict(1, s["pcoords_A"], max_dist=600.0)
+        ref = h2.predict_local(1, s["pcoords_A"], 600.0)[:2] if rank == 0 else None
+        h2.close()
+        q.put((rank, vres, pred, err, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_variogram_and_local_predictor_two_ranks_one_gpu():
+    """the lag-binning kernels with their pair tiles dealt out over two ranks, and the
+    local predictor with its points sharded -- the real HIP kernels, two processes on one GPU over gloo."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_vario_local, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < 2:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+            assert time.time() - t0 < 240, "timeout"
+    out.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("variogram")
+    for rank, vres, pred, err, ref in out:
+        for (i, j), (centers, edges, means, counts) in zip(((0, 0), (0, 1)), vres):
+            key = f"semi_1500_30_{i}{j}"
+            assert np.array_equal(counts, g[key + "_counts"])
+            np.testing.assert_allclose(centers, g[key + "_centers"], rtol=1e-12)
+            np.testing.assert_allclose(means, g[key + "_means"], rtol=1e-11, atol=1e-14)
+    ref_pred, ref_err = out[0][4]
+    for rank, vres, pred, err, ref in out:
+        assert np.array_equal(np.isnan(pred), np.isnan(ref_pred))
+        np.testing.assert_allclose(pred, ref_pred, rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(err, ref_err, rtol=1e-12, equal_nan=True)
