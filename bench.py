@@ -208,6 +208,12 @@ def main():
                 "solve_gemm_tflops": aux_update_flops(N, m) / aux_s / 1e12 if aux_s > 0 else None,
                 "cov_assembly_GBs": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9,
                 "cov_assembly_frac_of_hbm_peak": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9 / PEAK_HBM_GBS,
+                # 14 FP64 operations per tabulated entry (3 sub, mul, 2 fma: squared chord;
+                # sub: offset from the interval centre; 7 fma: Horner) against the 78.6 TF vector peak
+                "cov_assembly_frac_of_fp64_valu_peak": 14.0 * (N * (N + 1) / 2) / (tl["assemble_sigma_ms"] / 1e3) / 1e12
+                                                       / PEAK_F64_MFMA_TFLOPS,
+                # factor reused: grid-points/s of one more ck_predict on the resident L (K2 + K4 + reduce)
+                "amortised_grid_points_per_s": m / ((tl["assemble_aux_ms"] + tl["solve_ms"] + tl["reduce_ms"]) / 1e3),
             }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
