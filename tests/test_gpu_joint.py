@@ -389,3 +389,26 @@ def test_table_path_across_the_parameter_box(native, metric):
             np.testing.assert_allclose(low[0], low[1], rtol=5e-13, atol=5e-19 * scale, err_msg=str(pv))
         else:   # a gated-out table: the whole assembly went through the exact kernel
             assert np.array_equal(low[0], low[1]), pv
+
+
+@pytest.mark.parametrize("tag", ["A", "R"])
+def test_parity_in_units_of_the_oracles_own_perturbation_floor(native, tag):
+    """the tolerance made interpretable.  Nudging every input coordinate by one ulp moves
+    the ORACLE's predictions by `floor` (cond(Sigma) times rounding); the HIP path has to stay within a
+    small multiple of that floor (and of the 1e-6 the north star asks for by a wide margin)."""
+    g = load_golden("joint_solve")
+    coords = [g[f"coords0_{tag}"], g[f"coords1_{tag}"]]
+    values = [g[f"values0_{tag}"], g[f"values1_{tag}"]]
+    p = orc.Params.from_flat(g[f"params_{tag}"])
+    pc = g[f"pcoords_{tag}"]
+    ref, ref_err = orc.joint_predict(p, coords, values, pc, 0, HAV)
+    nudged = [np.nextafter(c, np.inf) for c in coords]
+    alt, alt_err = orc.joint_predict(p, nudged, values, np.nextafter(pc, np.inf), 0, HAV)
+    floor = max(rel(alt, ref), 1e-16)
+    cond = np.linalg.cond(orc.joint_cov(p, coords, HAV))
+    h, _ = _assembled(native, g[f"params_{tag}"], coords, values, HAV)
+    assert h.factor() == 0
+    pred, err = h.predict(0, pc)
+    e = rel(pred, ref)
+    print(f"set {tag}: cond(Sigma) = {cond:.3g}, oracle 1-ulp floor = {floor:.2e}, HIP vs oracle = {e:.2e}")
+    assert e < 1e-9 and e < 200.0 * floor + 1e-13
