@@ -29,3 +29,13 @@ print(json.dumps({"workload": f"config 5: {'cross-' if cross else ''}semivariogr
                   "pairs": pairs, "retained_pairs": int(counts.sum()), "wall_s": dt, "bin_pass_ms": tb,
                   "pairs_per_s_wall": pairs / dt, "pairs_per_s_bin_pass": pairs / (tb / 1e3),
                   "bin_mean_first3": means[:3].tolist(), "bin_count_first3": counts[:3].tolist()}))
+if "cpu" in sys.argv[2:]:
+    # the reference's dense-matrix path (oracle restatement) on this box's host cores, bounded sample
+    from oracle import cokrige_oracle as orc
+    nc = 8000
+    t0 = time.perf_counter()
+    orc.variogram(c0[:nc], v0[:nc], c0[:nc], v0[:nc], True, 0, 1500.0, 30)
+    dtc = time.perf_counter() - t0
+    print(json.dumps({"cpu_baseline": "oracle variogram (dense n x n distance / cloud matrices, numpy)", "n": nc,
+                      "pairs": nc * (nc - 1) // 2, "seconds": dtc, "pairs_per_s": nc * (nc - 1) / 2 / dtc,
+                      "cores": os.cpu_count()}))
