@@ -951,17 +951,17 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 // scaling L[i][j] = a[i][j] / sqrt(a[j][j]) is applied once at the end.  One barrier per step,
 // no LDS read-modify-write.
 // Then the inverse, for the row solves against this block (k_trsm64m: a product with L^-T on the
-// matrix cores instead of a 64-step substitution per row): L goes to LDS transposed and the first
-// wave solves X L^T = I, lane r holding row r of X = L^-T, i.e. column r of L^-1, in registers
-// (right-looking, multipliers of a step contiguous, read as ds_read_b128 broadcasts).
-// (Carrying the inverse along inside the 64 factorisation steps -- the same row operations applied
-// to an identity -- was measured: 35 us against 23 us + this phase.)
+// matrix cores instead of a 64-step substitution per row), blocked in 16 x 16 blocks (see below).
+// (Measured alternatives: one wave solving X L^T = I for all 64 columns by substitution, 36 us for the
+// whole kernel; carrying the inverse along inside the 64 factorisation steps -- the same row
+// operations applied to an identity -- 35 us.)
 // Linv: 64 x 64 row-major, lower triangle, upper zero.
 __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info,
                                                   double* __restrict__ Linv) {
     __shared__ double col[2][64];
     __shared__ double pv[64];
     __shared__ __attribute__((aligned(16))) double Lt[64][66];   // Lt[c][i] = L[i][c]
+    __shared__ __attribute__((aligned(16))) double Wi[64][66];   // the inverse, row-major
     __shared__ double rdiag[64];
     const int t = threadIdx.x, bi = t >> 4, bk = t & 15;
     const bool lower = bk <= bi;
@@ -1029,25 +1029,55 @@ __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld
             }
     }
     __syncthreads();
-    if (t >= 64) return;
-    // X L^T = I, lane r = row r of X (entries below... x[c] for c < r stay 0: uniform code, no branches)
-    double x[64];
+    // ---- the inverse, blocked 4 x 4 in 16 x 16 blocks ----
+    // A. the four diagonal blocks: wave b inverts D_b, lane r < 16 solving for column r of its inverse by
+    //    right-looking substitution (16 steps, multipliers broadcast from Lt);
+    // B. the blocks below the diagonal, by distance d = 1, 2, 3 from it, one wave per block on the matrix
+    //    cores:  W_ij = -W_ii (sum_{k = j}^{i - 1} L_ik W_kj).  The inner sum comes out of the MFMAs in
+    //    exactly the register layout the next MFMA wants for its B operand, so only finished blocks go
+    //    through LDS.
+    const int lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4;
+    {
+        const int o = 16 * wv;
+        double x[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) x[c] = (c == t) ? 1.0 : 0.0;
+        for (int c = 0; c < 16; ++c) x[c] = (c == li) ? 1.0 : 0.0;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        x[c] *= rdiag[c];
-        if (((c + 1) & 1) && c + 1 < 64) x[c + 1] -= x[c] * Lt[c][c + 1];
+        for (int c = 0; c < 16; ++c) {
+            x[c] *= rdiag[o + c];
 #pragma unroll
-        for (int c2 = (c + 2) & ~1; c2 < 64; c2 += 2) {
-            const d2_t m = *reinterpret_cast<const d2_t*>(&Lt[c][c2]);
-            x[c2] -= x[c] * m[0];
-            x[c2 + 1] -= x[c] * m[1];
+            for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= x[c] * Lt[o + c][o + c2];
+        }
+        if (lane < 16) {   // x[i] = D^-1[i][li]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Wi[o + i][o + li] = x[i];
         }
     }
-    // x[i] = (L^-T)[t][i] = Linv[i][t]: for fixed i the 64 lanes write 512 contiguous bytes
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 64; ++i) Linv[i * 64 + t] = x[i];
+    for (int d = 1; d < 4; ++d) {
+        const int i = wv + d, j = wv;            // wave wv takes block (wv + d, wv) of this level, if it exists
+        if (i < 4) {
+            d4_t tsum = {0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)   // A = L_ik[row li][kk], B = W_kj[kk][col li], kk = g + 4 s2
+                    tsum = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[16 * k + g + 4 * s2][16 * i + li],
+                                                               Wi[16 * k + g + 4 * s2][16 * j + li], tsum, 0, 0, 0);
+            d4_t w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)       // A = W_ii[row li][kk], B = tsum[kk][col li] = register s2 of tsum
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(Wi[16 * i + li][16 * i + g + 4 * s2], tsum[s2], w, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Wi[16 * i + g + 4 * r][16 * j + li] = -w[r];
+        }
+        __syncthreads();
+    }
+    // out: 64 x 64 row-major, the blocks above the diagonal are zero
+    for (int idx = t; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        Linv[idx] = ((c >> 4) <= (r >> 4)) ? Wi[r][c] : 0.0;
+    }
 }
 
 void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
