@@ -212,7 +212,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
- * "panel_group" (1..16, default 3) = panels per trailing update of ck_factor / ck_predict;
+ * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
+ * ck_factor / ck_predict;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit);
  * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and

@@ -126,7 +126,8 @@ struct ck_handle {
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
     // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
-    int panel_group = 3;
+    int panel_group = 0;   // 0 = automatic: 3 for 40 or more panels, else 1 (measured: the one-column in-group
+                           // launches cost more than the saved C traffic on small matrices)
     int gemm_variant = CK_GEMM_DEFAULT;   // option "gemm_variant"
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
@@ -834,6 +835,8 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     return 0;
 }
 
+static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 3 : 1); }
+
 static int factor_sweep(ck_handle* h) {
     h->gemm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -855,7 +858,7 @@ static int factor_sweep(ck_handle* h) {
             }
         }
         HIPCHK(hipGetLastError());
-    } else if (h->panel_group <= 1) {
+    } else if (eff_group(h) <= 1) {
         for (int K = 0; K < h->nK; ++K) {
             if (ck_panel_factor(h, K)) return -1;
             if (ck_panel_apply(h, K, CK_APPLY_SIGMA)) return -1;
@@ -864,7 +867,7 @@ static int factor_sweep(ck_handle* h) {
         // Groups of G panels: inside a group block column K first receives the updates of the group's
         // earlier panels in one pass (K dimension 512 g), then its panel step; the trailing matrix
         // beyond the group is updated once with K = 512 G -- a quarter of the C traffic of G = 1.
-        const int G = h->panel_group;
+        const int G = eff_group(h);
         for (int K0 = 0; K0 < h->nK; K0 += G) {
             const int Gc = std::min(G, h->nK - K0);
             for (int g = 0; g < Gc; ++g) {
@@ -904,11 +907,11 @@ static int solve_sweep(ck_handle* h) {
                 aux_update_on(h, K, h->sig[K], K + 2, h->nK - 1, M, true);
             }
         }
-    } else if (h->panel_group <= 1) {
+    } else if (eff_group(h) <= 1) {
         for (int K = 0; K < h->nK; ++K)
             if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
     } else {
-        const int G = h->panel_group;
+        const int G = eff_group(h);
         for (int K0 = 0; K0 < h->nK; K0 += G) {
             const int Gc = std::min(G, h->nK - K0);
             for (int g = 0; g < Gc; ++g) {
@@ -1559,7 +1562,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "panel_group")) {   // panels per trailing update (1 = after every panel)
-        if (value < 1 || value > 16) return fail("panel_group must be in [1, 16]");
+        if (value < 0 || value > 16) return fail("panel_group must be in [0, 16] (0 = automatic)");
         h->panel_group = (int)value;
         return 0;
     }
