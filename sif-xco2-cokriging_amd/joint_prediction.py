@@ -56,6 +56,7 @@ class Predictor:
         self.fast_dist = fast_dist
         self.device = device
         self.timings = {}
+        self.rhs_budget_bytes = 48 << 30   # device memory for the right-hand sides of one ck_predict call
         self._h = None
 
     # -- device state -------------------------------------------------------------------------
@@ -95,7 +96,16 @@ class Predictor:
         pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
         if cv_ix is None:
             h = self._factored_handle()
-            pred, err = h.predict(i, pc)
+            # The right-hand sides take (m + 1) x N doubles on the device: very large grids go through the
+            # resident factor in batches (one forward sweep each), sized by `rhs_budget_bytes`.
+            n_pad = h.num_panels()[2]
+            chunk = max(1024, int(self.rhs_budget_bytes // (8 * max(n_pad, 1))))
+            if len(pc) <= chunk:
+                pred, err = h.predict(i, pc)
+            else:
+                parts = [h.predict(i, pc[a:a + chunk]) for a in range(0, len(pc), chunk)]
+                pred = np.concatenate([p for p, _ in parts])
+                err = np.concatenate([e for _, e in parts])
             self.timings = h.timings()
         else:
             h = self._new_handle(drop=(i, cv_ix))

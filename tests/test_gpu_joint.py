@@ -273,6 +273,13 @@ def test_predictor_class_api(native):
     df = out.to_dataframe().reset_index() if hasattr(out, "to_dataframe") else out.reset_index()
     df = pc.merge(df, on=["lat", "lon"], how="left")
     assert rel(df["pred"].values, g["pred_A_1"]) < 1e-9
+    # a grid larger than the right-hand-side budget goes through the resident factor in batches
+    big = np.tile(g["pcoords_A"], (30, 1))[:2600]
+    whole = P.predict_arrays(1, big)
+    P.rhs_budget_bytes = 1      # -> batches of 1 024 points
+    batched = P.predict_arrays(1, big)
+    assert rel(batched[0], whole[0]) < 1e-12 and rel(batched[1], whole[1]) < 1e-12
+    P.rhs_budget_bytes = 48 << 30
     # model mirror
     hlag = np.array([0.0, 1.0, 50.0, 700.0])
     po = orc.Params.from_flat(g["params_A"])
