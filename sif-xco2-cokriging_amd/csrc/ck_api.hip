@@ -1171,17 +1171,18 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     if (k_max) *k_max = 0;
     if (m == 0) return 0;
     const int64_t mp = roundup(m, 64);
-    double *d_pc = nullptr, *d_p3 = nullptr, *d_out = nullptr, *d_slab = nullptr;
+    double *d_pc = nullptr, *d_p3 = nullptr, *d_pu = nullptr, *d_out = nullptr, *d_slab = nullptr;
     int* d_cnt = nullptr;
     long long* d_off = nullptr;
     HIPCHK(hipMalloc((void**)&d_pc, 2 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_p3, 3 * mp * 8));
+    HIPCHK(hipMalloc((void**)&d_pu, 3 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_out, 2 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_cnt, mp * sizeof(int)));
     HIPCHK(hipMalloc((void**)&d_off, mp * sizeof(long long)));
     HIPCHK(hipMemsetAsync(d_pc, 0, 2 * mp * 8, h->stream));
     HIPCHK(hipMemcpyAsync(d_pc, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
-    ck_launch_prep_sites(h->stream, d_pc, mp, h->metric, d_p3, d_p3 + mp, d_p3 + 2 * mp, nullptr);
+    ck_launch_prep_sites(h->stream, d_pc, mp, h->metric, d_p3, d_p3 + mp, d_p3 + 2 * mp, d_pu);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     ck_launch_local_count(h->stream, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, layout_of(h), d_cnt);
     HIPCHK(hipGetLastError());
@@ -1233,7 +1234,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
     for (const auto& bt : batches)
         ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, bt.first, bt.second - bt.first,
-                              mp, h->s0, h->z, layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp);
+                              mp, h->s0, h->z, layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp, h->d_tabs,
+                              h->d_coefptr, tables_usable(h) ? 1 : 0, h->su, d_pu);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(pred, d_out, m * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1250,6 +1252,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     if (k_max) *k_max = kmx;
     (void)hipFree(d_pc);
     (void)hipFree(d_p3);
+    (void)hipFree(d_pu);
     (void)hipFree(d_out);
     (void)hipFree(d_cnt);
     (void)hipFree(d_off);

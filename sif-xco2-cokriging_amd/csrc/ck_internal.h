@@ -130,5 +130,6 @@ void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double
 void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
-                           double* pred, double* err);
+                           double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
+                           const double* su, const double* pu);
 int ck_local_lds_limit();

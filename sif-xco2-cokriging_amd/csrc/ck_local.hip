@@ -34,6 +34,30 @@ __device__ __forceinline__ bool lp_is_neighbour(int metric, int cv, int i_pred, 
     return d <= max_dist;
 }
 
+// Covariance of a pair: through the block's table (ck_math.h "Tabulated covariance"; coefficients read from
+// global memory / L2 here -- three 48 KB tables do not fit next to the local system in LDS) when the pair's
+// squared chord is inside the table, else the exact evaluator (closer than the table's lower end incl.
+// h == 0 and the nugget, beyond its upper end, or tables disabled).  The exact Bessel evaluation of every
+// entry was 85 % of this path's time at a few hundred neighbours.
+struct LpTab {
+    const CkTable* tabs;             // [3]
+    const double* const* coefs;      // [3]
+    int use;
+};
+
+__device__ __forceinline__ double lp_cov(const CkMatern* blk, const LpTab& T, int bidx, int nug, int metric, double a0,
+                                         double a1, double a2, double au0, double au1, double au2, double b0, double b1,
+                                         double b2, double bu0, double bu1, double bu2) {
+    if (T.use) {
+        const double dx = au0 - bu0, dy = au1 - bu1, dz = au2 - bu2;
+        const double q = dx * dx + dy * dy + dz * dz;
+        int iv;
+        const double y = ck_table_y(q, &iv, T.tabs[bidx].base);
+        if ((unsigned)iv < (unsigned)T.tabs[bidx].n_int) return ck_table_poly(T.coefs[bidx], iv, y);
+    }
+    return ck_cov_entry(blk[bidx], lp_dist(metric, a0, a1, a2, b0, b1, b2), nug);
+}
+
 // neighbour count per prediction point
 __global__ __launch_bounds__(LP_TPB) void k_local_count(int metric, int i_pred, int cv, double max_dist,
                                                          const double* __restrict__ pc, long mpad,
@@ -63,7 +87,8 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
                                                          const long long* __restrict__ slab_off,
                                                          double* __restrict__ slab, double c0var,
                                                          double* __restrict__ pred, double* __restrict__ err,
-                                                         long p_base) {
+                                                         long p_base, LpTab T, const double* __restrict__ su,
+                                                         const double* __restrict__ pu) {
     __shared__ double lS[(LP_KL + 2) * LP_KL];
     __shared__ int lidx[LP_KL];
     __shared__ int wsum[LP_TPB / 64];
@@ -82,6 +107,8 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
     if (k > LP_KL) return;   // larger systems: k_local_solve_big
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
+    const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;        // chord vectors (table path)
+    const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
     // storage: (k + 2) x k matrix (rows k, k + 1 carry c and z) and the neighbour index list
     double* S = lS;
     int* idx = lidx;
@@ -114,14 +141,14 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
         const long b = e - a * (a + 1) / 2;
         const long ga = idx[a], gb = idx[b];
         const int pa = ga >= L.n0p, pb = gb >= L.n0p;
-        const double d = lp_dist(metric, s0[ga], s1[ga], s2[ga], s0[gb], s1[gb], s2[gb]);
-        S[a * ld + b] = ck_cov_entry(blk[pa + pb], d, pa == pb);
+        S[a * ld + b] = lp_cov(blk, T, pa + pb, pa == pb, metric, s0[ga], s1[ga], s2[ga], u0[ga], u1[ga], u2[ga], s0[gb],
+                               s1[gb], s2[gb], u0[gb], u1[gb], u2[gb]);
     }
     for (int a = tid; a < k; a += LP_TPB) {
         const long ga = idx[a];
         const int pa = ga >= L.n0p;
-        const double d = lp_dist(metric, p0, p1, p2, s0[ga], s1[ga], s2[ga]);
-        S[(long)k * ld + a] = ck_cov_entry(blk[i_pred + pa], d, pa == i_pred);   // point_prediction.py:115-125
+        S[(long)k * ld + a] = lp_cov(blk, T, i_pred + pa, pa == i_pred, metric, p0, p1, p2, q0, q1, q2, s0[ga], s1[ga],
+                                     s2[ga], u0[ga], u1[ga], u2[ga]);   // point_prediction.py:115-125
         S[(long)(k + 1) * ld + a] = z[ga];
     }
     __syncthreads();
@@ -190,7 +217,8 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
 // one pass over the trailing matrix per COLUMN: k / LB_IB times the memory traffic (it measured
 // 0.4 TFLOP/s at k = 1 359).
 #define LB_IB 32
-__global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __restrict__ blk, int metric, int i_pred,
+#define LB_PR 128   // panel rows per pass; LB_IB * (LB_PR + 1) <= 2 * LB_IB * 68 doubles of LDS
+__global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* __restrict__ blk, int metric, int i_pred,
                                                              int cv, double max_dist,
                                                              const double* __restrict__ pc, long mpad,
                                                              const double* __restrict__ sc,
@@ -199,9 +227,14 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __re
                                                              const long long* __restrict__ slab_off,
                                                              double* __restrict__ slab, double c0var,
                                                              double* __restrict__ pred, double* __restrict__ err,
-                                                             long p_base) {
-    __shared__ __attribute__((aligned(16))) double At[LB_IB][64 + 4];   // At[c][r] = strip of the tile's rows
-    __shared__ __attribute__((aligned(16))) double Bt[LB_IB][64 + 4];   // Bt[c][r] = strip of the tile's columns
+                                                             long p_base, LpTab T, const double* __restrict__ su,
+                                                             const double* __restrict__ pu) {
+    __shared__ __attribute__((aligned(16))) double lbuf[2 * LB_IB * (64 + 4)];
+    double (*At)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf);                 // At[c][r] = strip of the tile's rows
+    double (*Bt)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf + LB_IB * (64 + 4));   // Bt[c][r] = ... columns
+    double (*Pt)[LB_PR + 1] = reinterpret_cast<double (*)[LB_PR + 1]>(lbuf);           // panel rows (3a), same storage
+    __shared__ double Ld[LB_IB][LB_IB + 1];   // diagonal block of the column panel
+    __shared__ double rdiag[LB_IB], Ldiag[LB_IB];
     __shared__ int wsum[LP_TPB / 64];
     __shared__ int fail;
     __shared__ double red[2][LP_TPB];
@@ -211,6 +244,8 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __re
     if (k <= LP_KL) return;   // k_local_solve (also the empty neighbourhoods)
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
+    const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;        // chord vectors (table path)
+    const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
     double* S = slab + slab_off[p];   // (k + 2) x k, rows k and k + 1 carry c and z
     int* idx = reinterpret_cast<int*>(S + (long)(k + 2) * k);
     const long ld = k;
@@ -236,19 +271,19 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __re
     for (int a = 0; a < k; ++a) {   // row by row: coalesced writes, no sqrt to invert the triangular index
         const long ga = idx[a];
         const int pa = ga >= L.n0p;
-        const double a0 = s0[ga], a1 = s1[ga], a2 = s2[ga];
+        const double a0 = s0[ga], a1 = s1[ga], a2 = s2[ga], au0 = u0[ga], au1 = u1[ga], au2 = u2[ga];
         for (int b = tid; b <= a; b += LP_TPB) {
             const long gb = idx[b];
             const int pb = gb >= L.n0p;
-            const double d = lp_dist(metric, a0, a1, a2, s0[gb], s1[gb], s2[gb]);
-            S[(long)a * ld + b] = ck_cov_entry(blk[pa + pb], d, pa == pb);
+            S[(long)a * ld + b] = lp_cov(blk, T, pa + pb, pa == pb, metric, a0, a1, a2, au0, au1, au2, s0[gb], s1[gb], s2[gb],
+                                         u0[gb], u1[gb], u2[gb]);
         }
     }
     for (int a = tid; a < k; a += LP_TPB) {
         const long ga = idx[a];
         const int pa = ga >= L.n0p;
-        const double d = lp_dist(metric, p0, p1, p2, s0[ga], s1[ga], s2[ga]);
-        S[(long)k * ld + a] = ck_cov_entry(blk[i_pred + pa], d, pa == i_pred);   // point_prediction.py:115-125
+        S[(long)k * ld + a] = lp_cov(blk, T, i_pred + pa, pa == i_pred, metric, p0, p1, p2, q0, q1, q2, s0[ga], s1[ga],
+                                     s2[ga], u0[ga], u1[ga], u2[ga]);   // point_prediction.py:115-125
         S[(long)(k + 1) * ld + a] = z[ga];
     }
     __syncthreads();
@@ -258,31 +293,67 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve_big(const CkMatern* __re
     for (int jb = 0; jb < k && !bad; jb += LB_IB) {
         const int nbc = (k - jb < LB_IB) ? (k - jb) : LB_IB;
         const int jend = jb + nbc;
-        // 3a. the column panel jb .. jend - 1, all rows below
-        for (int j = jb; j < jend; ++j) {
-            const double piv = S[(long)j * ld + j];
+        // 3a. the column panel jb .. jend - 1: its diagonal block is factored in LDS (padded to LB_IB with the
+        //     identity), then every row below is solved against it -- one thread per row, the row's LB_IB
+        //     entries in registers, LB_PR rows per pass staged through LDS so that global memory sees whole
+        //     256-byte row segments.  (Column-at-a-time on the slab walked it with a stride of k doubles:
+        //     one cache line per entry, k times over -- half of this kernel's time at k = 1 359.)
+        for (int e = tid; e < LB_IB * LB_IB; e += LP_TPB) {
+            const int r = e / LB_IB, c = e % LB_IB;
+            Ld[r][c] = (r < nbc && c <= r) ? S[(long)(jb + r) * ld + jb + c] : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        for (int j = 0; j < LB_IB; ++j) {
+            const double piv = Ld[j][j];
             if (!(piv > 0.0)) {   // uniform: every thread reads the same pivot
                 if (tid == 0) fail = 1;
                 bad = true;
                 break;
             }
             const double rd = 1.0 / sqrt(piv);
+            if (tid > j && tid < LB_IB) Ld[tid][j] *= rd;
+            if (tid == 0) {
+                rdiag[j] = rd;
+                Ldiag[j] = sqrt(piv);
+            }
             __syncthreads();
-            for (int a = j + 1 + tid; a < k + 2; a += LP_TPB) S[(long)a * ld + j] *= rd;
-            if (tid == 0) S[(long)j * ld + j] = sqrt(piv);
-            __syncthreads();
-            const int nbp = jend - 1 - j;        // panel columns b = j + 1 .. jend - 1
-            const int na = k + 1 - j;            // rows a = j + 1 .. k + 1
-            if (nbp > 0) {
-                const long tot = (long)na * nbp;
-                for (long e = tid; e < tot; e += LP_TPB) {
-                    const int a = j + 1 + (int)(e / nbp), b = j + 1 + (int)(e % nbp);
-                    if (b <= a) S[(long)a * ld + b] -= S[(long)a * ld + j] * S[(long)b * ld + j];
-                }
+            for (int e = tid; e < LB_IB * LB_IB; e += LP_TPB) {
+                const int a = e / LB_IB, b = e % LB_IB;
+                if (b > j && a >= b) Ld[a][b] -= Ld[a][j] * Ld[b][j];
             }
             __syncthreads();
         }
         if (bad) break;
+        for (int e = tid; e < LB_IB * LB_IB; e += LP_TPB) {
+            const int r = e / LB_IB, c = e % LB_IB;
+            if (r < nbc && c <= r) S[(long)(jb + r) * ld + jb + c] = (r == c) ? Ldiag[r] : Ld[r][c];
+        }
+        for (int r0 = jend; r0 < k + 2; r0 += LB_PR) {
+            for (int e = tid; e < LB_PR * LB_IB; e += LP_TPB) {
+                const int r = e / LB_IB, c = e % LB_IB, a = r0 + r;
+                Pt[c][r] = (a < k + 2 && c < nbc) ? S[(long)a * ld + jb + c] : 0.0;
+            }
+            __syncthreads();
+            if (tid < LB_PR) {
+                double x[LB_IB];
+#pragma unroll
+                for (int c = 0; c < LB_IB; ++c) x[c] = Pt[c][tid];
+#pragma unroll
+                for (int j = 0; j < LB_IB; ++j) {
+                    x[j] *= rdiag[j];
+#pragma unroll
+                    for (int c = j + 1; c < LB_IB; ++c) x[c] -= x[j] * Ld[c][j];
+                }
+#pragma unroll
+                for (int c = 0; c < LB_IB; ++c) Pt[c][tid] = x[c];
+            }
+            __syncthreads();
+            for (int e = tid; e < LB_PR * LB_IB; e += LP_TPB) {
+                const int r = e / LB_IB, c = e % LB_IB, a = r0 + r;
+                if (a < k + 2 && c < nbc) S[(long)a * ld + jb + c] = Pt[c][r];
+            }
+            __syncthreads();
+        }
         // 3b. trailing update  S[a][b] -= sum_c S[a][jb + c] S[b][jb + c],  a in [jend, k + 2), b in [jend, min(a, k - 1)]
         const int nrow = k + 2 - jend, ncol = k - jend;
         const int tr = (nrow + 63) / 64, tc = (ncol + 63) / 64;
@@ -365,14 +436,16 @@ void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double
 void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
-                           double* pred, double* err) {
+                           double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
+                           const double* su, const double* pu) {
     if (m <= 0) return;
+    const LpTab T{tabs, coefs, use_tab};
     k_local_solve<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                             counts, slab_off, slab, c0var, pred, err, p_base);
+                                                             counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu);
     if (slab)   // some neighbourhood is larger than the LDS limit
         k_local_solve_big<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z,
                                                                      L, counts, slab_off, slab, c0var, pred, err,
-                                                                     p_base);
+                                                                     p_base, T, su, pu);
 }
 
 int ck_local_lds_limit() { return LP_KL; }
