@@ -13,6 +13,10 @@ h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
 h.set_metric(0)
 for k in range(2):
     h.set_data(k, pb["coords"][k], pb["values"][k])
+if os.environ.get("CK_LOCAL_TILE_MIN"):   # A/B of the size-class boundary (default 256)
+    h.set_option("local_tile_min", int(os.environ["CK_LOCAL_TILE_MIN"]))
+if os.environ.get("CK_LOCAL_GROUP"):
+    h.set_option("local_group", int(os.environ["CK_LOCAL_GROUP"]))
 out = []
 for md in [float(x) for x in (sys.argv[2:] or ["50", "100", "200", "400"])]:
     h.predict_local(0, pb["pcoords"][:64], md)          # warm-up (layout, tables)
@@ -23,4 +27,6 @@ for md in [float(x) for x in (sys.argv[2:] or ["50", "100", "200", "400"])]:
     info = res[2] if len(res) > 2 else {}
     out.append({"max_dist_km": md, "points": len(pred), "seconds": dt, "points_per_s": len(pred) / dt,
                 "finite": int(np.isfinite(pred).sum()), "info": {k: int(v) for k, v in dict(info).items()} if info else None})
+    out[-1]["checksum"] = float(np.nansum(pred))
+    out[-1]["device_ms"] = h.timings()["local_ms"]   # HIP events around the kernels (the wall time adds allocation and copies)
     print(json.dumps(out[-1]), flush=True)

@@ -130,6 +130,8 @@ struct ck_handle {
                            // launches cost more than the saved C traffic on small matrices)
     int gemm_variant = CK_GEMM_DEFAULT;   // option "gemm_variant"
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
+    int local_tile_min = 256;    // option "local_tile_min": neighbourhoods larger than this take the tiled path
+    int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
@@ -1173,7 +1175,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     const int64_t mp = roundup(m, 64);
     double *d_pc = nullptr, *d_p3 = nullptr, *d_pu = nullptr, *d_out = nullptr, *d_slab = nullptr;
     int* d_cnt = nullptr;
-    long long* d_off = nullptr;
+    long long *d_off = nullptr, *d_linfo = nullptr;
+    CkLocalSys* d_sys = nullptr;
     HIPCHK(hipMalloc((void**)&d_pc, 2 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_p3, 3 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_pu, 3 * mp * 8));
@@ -1189,21 +1192,31 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     std::vector<int> cnt(m);
     HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    // Scratch slabs for neighbourhoods beyond the LDS limit.  The points are processed in consecutive
-    // batches whose slabs fit a budget (a quarter of the free device memory, at most 32 GiB), so that
-    // large radii over many points do not need sum_p k_p^2 doubles at once.
+    // Scratch slabs for neighbourhoods beyond the LDS limit.  Three size classes:
+    //   k <= LDS limit               k_local_solve, system in LDS
+    //   k <= local_tile_min          k_local_solve_big, one workgroup per point on a slab in global memory
+    //   larger                       the tiled path (ck_internal.h: CkLocalSys): a batch of systems factored
+    //                                together, three launches per 64 columns, updates on the MFMA tiles
+    // Both slab users work in batches that fit a budget (a quarter of the free device memory, at most 32 GiB),
+    // so that large radii over many points do not need sum_p k_p^2 doubles at once.
     const int kl = ck_local_lds_limit();
+    const int k_hi = std::max(kl, h->local_tile_min);
     std::vector<long long> off(m, 0), need(m, 0);
+    std::vector<int64_t> tiled;   // points of the third class
     int64_t kmx = 0, nempty = 0;
     long long need_max = 0;
     for (int64_t p = 0; p < m; ++p) {
         const long long k = cnt[p];
         kmx = k > kmx ? k : kmx;
         if (k == 0) ++nempty;
-        if (k > kl) {
-            need[p] = ((k + 2) * k + (k + 1) / 2 + 2 + 1) & ~1LL;   // matrix + index list (ints), kept 16-byte aligned
-            need_max = need[p] > need_max ? need[p] : need_max;
+        long long nd = 0;
+        if (k > k_hi) {
+            tiled.push_back(p);
+            nd = ck_local_tiled_doubles(k);
+        } else if (k > kl) {
+            nd = need[p] = ((k + 2) * k + (k + 1) / 2 + 2 + 1) & ~1LL;   // matrix + index list (ints), kept 16-byte aligned
         }
+        need_max = nd > need_max ? nd : need_max;
     }
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
@@ -1229,13 +1242,64 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
         batches.push_back({b0, m});
         slab_doubles = acc > slab_doubles ? acc : slab_doubles;
     }
+    // tiled class: largest neighbourhoods first, so that the systems still active at a column are a prefix
+    std::sort(tiled.begin(), tiled.end(), [&](int64_t a, int64_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+    std::vector<CkLocalSys> sysv(tiled.size());
+    std::vector<std::pair<size_t, size_t>> tbatches;
+    {
+        size_t b0 = 0;
+        long long acc = 0;
+        for (size_t t = 0; t < tiled.size(); ++t) {
+            const long long k = cnt[tiled[t]], nd = ck_local_tiled_doubles(k);
+            if (acc + nd > budget && t > b0) {
+                tbatches.push_back({b0, t});
+                slab_doubles = acc > slab_doubles ? acc : slab_doubles;
+                b0 = t;
+                acc = 0;
+            }
+            const int kq = (int)((k + 63) / 64 * 64);
+            sysv[t] = CkLocalSys{acc, (int)k, kq, kq + 128, (int)tiled[t]};
+            acc += nd;
+        }
+        if (!tiled.empty()) {
+            tbatches.push_back({b0, tiled.size()});
+            slab_doubles = acc > slab_doubles ? acc : slab_doubles;
+        }
+    }
     if (slab_doubles > 0) HIPCHK(hipMalloc((void**)&d_slab, (size_t)slab_doubles * 8));
     HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
+    const int use_tab = tables_usable(h) ? 1 : 0;
     for (const auto& bt : batches)
         ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, bt.first, bt.second - bt.first,
                               mp, h->s0, h->z, layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp, h->d_tabs,
-                              h->d_coefptr, tables_usable(h) ? 1 : 0, h->su, d_pu);
+                              h->d_coefptr, use_tab, h->su, d_pu, k_hi);
+    HIPCHK(hipGetLastError());
+    if (!tiled.empty()) {
+        HIPCHK(hipMalloc((void**)&d_sys, sysv.size() * sizeof(CkLocalSys)));
+        HIPCHK(hipMalloc((void**)&d_linfo, sysv.size() * sizeof(long long)));
+        HIPCHK(hipMemcpyAsync(d_sys, sysv.data(), sysv.size() * sizeof(CkLocalSys), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(d_linfo, 0, sysv.size() * sizeof(long long), h->stream));
+        for (const auto& tb : tbatches) {
+            const CkLocalSys* bsys = d_sys + tb.first;
+            const int nb = (int)(tb.second - tb.first);
+            ck_launch_local_assemble_t(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, mp, h->s0, h->z,
+                                       layout_of(h), bsys, nb, d_slab, h->d_tabs, h->d_coefptr, use_tab, h->su, d_pu);
+            const int kq_max = sysv[tb.first].kq;
+            int na = nb;
+            const int G = h->local_group;
+            for (int g0 = 0; g0 < kq_max; g0 += 64 * G) {
+                for (int b = 0; b < G && g0 + 64 * b < kq_max; ++b) {
+                    while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * b) --na;   // finished systems drop off the end
+                    ck_launch_local_tiled_block(h->stream, bsys, d_slab, na, g0, b, kq_max, d_linfo + tb.first);
+                }
+                while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * G) --na;
+                ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kq_max);
+            }
+            ck_launch_local_reduce_t(h->stream, bsys, nb, d_slab, d_linfo + tb.first, c0var, d_out, d_out + mp);
+            HIPCHK(hipGetLastError());
+        }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(pred, d_out, m * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1257,6 +1321,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     (void)hipFree(d_cnt);
     (void)hipFree(d_off);
     if (d_slab) (void)hipFree(d_slab);
+    if (d_sys) (void)hipFree(d_sys);
+    if (d_linfo) (void)hipFree(d_linfo);
     return 0;
 }
 
@@ -1562,6 +1628,16 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "local_slab_mb")) {
         if (value < 0) return fail("local_slab_mb must be >= 0");
         h->local_slab_mb = value;
+        return 0;
+    }
+    if (!strcmp(name, "local_group")) {
+        if (value < 1 || value > 16) return fail("local_group must be in [1, 16]");
+        h->local_group = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "local_tile_min")) {   // see ck_handle::local_tile_min
+        if (value < 0) return fail("local_tile_min must be >= 0");
+        h->local_tile_min = (int)std::min<int64_t>(value, 1 << 30);
         return 0;
     }
     if (!strcmp(name, "panel_group")) {   // panels per trailing update (1 = after every panel)

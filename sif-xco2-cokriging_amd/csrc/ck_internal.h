@@ -131,5 +131,40 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
                            double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
-                           const double* su, const double* pu);
+                           const double* su, const double* pu, int k_hi);
 int ck_local_lds_limit();
+
+// Large neighbourhoods (k > k_hi above): the "tiled" path.  The systems of a batch are factored TOGETHER,
+// 64 columns per step, by three launches per step over all systems that still have columns left (diagonal
+// block + its inverse, row solves, trailing update on 128 x 128 MFMA tiles) -- the tile kernels of the joint
+// path with a system index in blockIdx.y.  A system's scratch (slab + off):
+//   S     CK_LT_ROWS(kq) rows x ld doubles, ld = kq + 128, kq = k rounded up to 64.  Rows/cols [0, k): local
+//         covariance (lower triangle); [k, kq): identity padding; rows kq, kq + 1: the c and z rows, which
+//         ride along as in the other local kernels.  The 128 rows / columns beyond exist only so that whole
+//         tiles can be read and written without bounds checks; nothing valid depends on them.
+//   Linv  64 x 64 doubles (inverse of the current diagonal block)
+//   idx   k ints (neighbour list)
+struct CkLocalSys {
+    long long off;      // doubles into the slab
+    int k, kq, ld, p;   // neighbours, padded size, leading dimension, prediction point index
+};
+#define CK_LT_ROWS(kq) ((kq) + 130)
+static inline long long ck_local_tiled_doubles(long long k) {
+    const long long kq = (k + 63) / 64 * 64;
+    return (CK_LT_ROWS(kq) * (kq + 128) + 64 * 64 + (k + 1) / 2 + 1) & ~1LL;
+}
+void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
+                                const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
+                                const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
+                                const double* const* coefs, int use_tab, const double* su, const double* pu);
+// Columns are processed in groups of g 64-column blocks [g0, g0 + 64 g): block i of a group first receives the
+// updates of the group's earlier blocks (one pass, K = 64 i), then its diagonal block is factored and inverted and
+// the rows below are solved; the trailing matrix behind the group is updated once with K = 64 g (a g-th of the
+// read-modify-write traffic of updating after every block).  Systems sorted by k descending: the first n_active
+// are the ones that still have the block / trailing columns in question.
+void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
+                                 int kq_max, long long* info);
+void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
+                                    int kq_max);
+void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,
+                              const long long* info, double c0var, double* pred, double* err);

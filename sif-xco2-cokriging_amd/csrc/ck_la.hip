@@ -956,12 +956,11 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 // whole kernel; carrying the inverse along inside the 64 factorisation steps -- the same row
 // operations applied to an identity -- 35 us.)
 // Linv: 64 x 64 row-major, lower triangle, upper zero.
-__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info,
-                                                  double* __restrict__ Linv) {
+// Lt, Wi: two 64 x 66 LDS arrays (Lt[c][i] = L[i][c]; Wi = the inverse, row-major) owned by the calling kernel
+__device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, long g0, long long* info,
+                                             double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66]) {
     __shared__ double col[2][64];
     __shared__ double pv[64];
-    __shared__ __attribute__((aligned(16))) double Lt[64][66];   // Lt[c][i] = L[i][c]
-    __shared__ __attribute__((aligned(16))) double Wi[64][66];   // the inverse, row-major
     __shared__ double rdiag[64];
     const int t = threadIdx.x, bi = t >> 4, bk = t & 15;
     const bool lower = bk <= bi;
@@ -1080,6 +1079,13 @@ __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld
     }
 }
 
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info,
+                                                  double* __restrict__ Linv) {
+    __shared__ __attribute__((aligned(16))) double Lt[64][66];
+    __shared__ __attribute__((aligned(16))) double Wi[64][66];
+    potrf64_body(A, ld, g0, info, Linv, Lt, Wi);
+}
+
 void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
                        double* Linv) {
     k_potrf64<<<dim3(1), dim3(256), 0, s>>>(A, ld, global_index0, info_dev, Linv);
@@ -1093,13 +1099,12 @@ void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_inde
 // of X; Linv is lower triangular, so column tile jt needs k < 16 (jt + 1) only: 40 MFMA 16x16x4 per
 // wave.  (The first version kept one row per lane in registers and substituted through 64 steps of
 // LDS-broadcast multipliers, rows read as 512 contiguous bytes PER LANE: 27 us per launch.)
-__global__ __launch_bounds__(256, 2) void k_trsm64m(double* __restrict__ A, long ld, long nrows,
-                                                     const double* __restrict__ Linv) {
+__device__ __forceinline__ void trsm64_body(double* __restrict__ A, long ld, long row0,
+                                            const double* __restrict__ Linv) {
     constexpr int PITCH = 66;   // doubles per LDS row
     __shared__ __attribute__((aligned(16))) double As[64 * PITCH];
     __shared__ __attribute__((aligned(16))) double Li[64 * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long row0 = (long)blockIdx.x * 64;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
         As[r * PITCH + c] = A[(row0 + r) * ld + c];
@@ -1121,9 +1126,176 @@ __global__ __launch_bounds__(256, 2) void k_trsm64m(double* __restrict__ A, long
     }
 }
 
+__global__ __launch_bounds__(256, 2) void k_trsm64m(double* __restrict__ A, long ld, long nrows,
+                                                     const double* __restrict__ Linv) {
+    trsm64_body(A, ld, (long)blockIdx.x * 64, Linv);
+}
+
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* Linv) {
     if (nrows <= 0) return;
     k_trsm64m<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(A, ld, nrows, Linv);   // nrows is a multiple of 64 (host)
+}
+
+// ---------------------------------------------------------------------------------------
+// local-neighbourhood systems, tiled path (ck_internal.h: CkLocalSys): one 64-column step for a
+// batch of independent systems, system index in blockIdx.y
+// ---------------------------------------------------------------------------------------
+// One 64-row chunk of block column i of the group that starts at column g0 (jb = g0 + 64 i): first the updates
+// of the group's earlier blocks (left-looking inside the group),
+//     C[rows, jb .. jb + 63] -= S[rows, g0 .. jb) * S[jb .. jb + 63, g0 .. jb)^T,
+// then, with SOLVE, the row solve against the factored diagonal block as a product with its inverse,
+//     X = C Linv^T,
+// in one pass over the chunk.  K slabs of 64 columns are staged through LDS with the next slab already in
+// flight in registers; the chunk of C is loaded straight into the MFMA result layout before the K loop.
+// As, Bs: 64 x 66 doubles of LDS each.
+template <bool SOLVE>
+__device__ __forceinline__ void lt_rows_body(double* __restrict__ S, long ld, int g0, int i, int row0,
+                                             const double* __restrict__ Linv, double* As, double* Bs) {
+    constexpr int PITCH = 66;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int jb = g0 + 64 * i;
+    const double* Ar = S + (long)row0 * ld + g0;
+    const double* Br = S + (long)jb * ld + g0;
+    double* C = S + (long)row0 * ld + jb;
+    const int sr = tid >> 6, sc = tid & 63;   // staging: element (sr + 4 u, sc), u < 16
+    double ra[16], rb[16];
+    if (i > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
+            rb[u] = Br[(long)(sr + 4 * u) * ld + sc];
+        }
+    }
+    d4_t cn[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cn[jt][r] = C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li];
+    for (int ks = 0; ks < i; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            As[(sr + 4 * u) * PITCH + sc] = -ra[u];
+            Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+        }
+        __syncthreads();
+        if (ks + 1 < i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
+                rb[u] = Br[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
+            }
+        } else if (SOLVE) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rb[u] = Linv[(sr + 4 * u) * 64 + sc];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const double av = As[(16 * w + li) * PITCH + 4 * s2 + g];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                cn[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[(16 * jt + li) * PITCH + 4 * s2 + g], cn[jt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (!SOLVE) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = cn[jt][r];
+        return;
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) rb[u] = Linv[(sr + 4 * u) * 64 + sc];
+    }
+    // the updated chunk becomes the A operand (each wave re-reads only the 16 rows it wrote), Linv the B operand
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) As[(16 * w + g + 4 * r) * PITCH + 16 * jt + li] = cn[jt][r];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4 * (jt + 1); ++s2)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * w + li) * PITCH + 4 * s2 + g],
+                                                      Bs[(16 * jt + li) * PITCH + 4 * s2 + g], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = acc[r];
+    }
+}
+
+// diagonal block of block column jb = g0 + 64 i: its in-group update, then the factorisation and the inverse
+__global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
+                                                     int i, long long* info) {
+    __shared__ __attribute__((aligned(16))) double Lt[64][66];
+    __shared__ __attribute__((aligned(16))) double Wi[64][66];
+    const CkLocalSys q = sys[blockIdx.x];
+    double* S = slab + q.off;
+    const int jb = g0 + 64 * i;
+    if (i > 0) {
+        lt_rows_body<false>(S, q.ld, g0, i, jb, nullptr, &Lt[0][0], &Wi[0][0]);
+        __syncthreads();   // the block is re-read from memory by other threads of this workgroup
+    }
+    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, Lt, Wi);
+}
+
+// rows below the diagonal block: in-group update and row solve
+__global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
+                                                     int i) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    const CkLocalSys q = sys[blockIdx.y];
+    const int jb = g0 + 64 * i;
+    const int nchunk = (q.kq + 2 - jb - 64 + 63) / 64;   // rows jb + 64 .. kq + 1
+    if ((int)blockIdx.x >= nchunk) return;
+    double* S = slab + q.off;
+    lt_rows_body<true>(S, q.ld, g0, i, jb + 64 + 64 * (int)blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, As, Bs);
+}
+
+// trailing update behind a group of columns [g0, g0 + K):  C -= A A^T on 128 x 128 tiles, rows g0 + K .. kq + 1,
+// columns g0 + K .. kq - 1, lower tiles only.  All tiles of a system run on one XCD (they share the A rows through
+// its L2): with workgroups dealt out to the 8 XCDs round-robin by linear id, system y' = 8 (id / (8 GX)) + id % 8.
+__global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restrict__ sys, double* __restrict__ slab,
+                                                       int g0, int K, int n_active) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int GX = gridDim.x;
+    const int lin = blockIdx.x + blockIdx.y * GX;
+    const int y = 8 * (lin / (8 * GX)) + (lin & 7), t = (lin >> 3) % GX;
+    if (y >= n_active) return;
+    const CkLocalSys q = sys[y];
+    const int o = g0 + K;
+    const int T = (q.kq + 2 - o + 127) / 128, Tc = (q.kq - o + 127) / 128;
+    if (t >= T * (T + 1) / 2) return;
+    int tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (tm * (tm + 1) / 2 > t) --tm;
+    while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+    const int tn = t - tm * (tm + 1) / 2;
+    if (tn >= Tc) return;
+    double* S = slab + q.off;
+    const double* A = S + (long)o * q.ld + g0;
+    gemm_tile_e<0>(S + (long)o * q.ld + o, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, K, lds);
+}
+
+// block i of the group at g0 for the first n_active systems (those with kq > g0 + 64 i)
+void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
+                                 int kq_max, long long* info) {
+    if (n_active <= 0) return;
+    k_lt_potrf64<<<dim3((unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, info);
+    const int rows = kq_max + 2 - (g0 + 64 * i) - 64;   // >= 2: the c and z rows
+    k_lt_rows<<<dim3((unsigned)((rows + 63) / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i);
+}
+
+// trailing update behind the group [g0, g0 + K) for the first n_active systems (those with kq > g0 + K)
+void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
+                                    int kq_max) {
+    if (n_active <= 0 || kq_max - g0 - K <= 0) return;
+    const int T = (kq_max + 2 - g0 - K + 127) / 128;
+    k_lt_update<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)((n_active + 7) / 8 * 8)), dim3(512), 0, s>>>(sys, slab, g0, K,
+                                                                                                      n_active);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -37,8 +37,7 @@ __device__ __forceinline__ bool lp_is_neighbour(int metric, int cv, int i_pred, 
 // Covariance of a pair: through the block's table (ck_math.h "Tabulated covariance"; coefficients read from
 // global memory / L2 here -- three 48 KB tables do not fit next to the local system in LDS) when the pair's
 // squared chord is inside the table, else the exact evaluator (closer than the table's lower end incl.
-// h == 0 and the nugget, beyond its upper end, or tables disabled).  The exact Bessel evaluation of every
-// entry was 85 % of this path's time at a few hundred neighbours.
+// h == 0 and the nugget, beyond its upper end, or tables disabled).
 struct LpTab {
     const CkTable* tabs;             // [3]
     const double* const* coefs;      // [3]
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* _
                                                              double* __restrict__ slab, double c0var,
                                                              double* __restrict__ pred, double* __restrict__ err,
                                                              long p_base, LpTab T, const double* __restrict__ su,
-                                                             const double* __restrict__ pu) {
+                                                             const double* __restrict__ pu, int k_hi) {
     __shared__ __attribute__((aligned(16))) double lbuf[2 * LB_IB * (64 + 4)];
     double (*At)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf);                 // At[c][r] = strip of the tile's rows
     double (*Bt)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf + LB_IB * (64 + 4));   // Bt[c][r] = ... columns
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* _
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long p = p_base + blockIdx.x;
     const int k = counts[p];
-    if (k <= LP_KL) return;   // k_local_solve (also the empty neighbourhoods)
+    if (k <= LP_KL || k > k_hi) return;   // k_local_solve (also the empty neighbourhoods) / the tiled path
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
     const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;        // chord vectors (table path)
@@ -437,15 +436,144 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
                            double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
-                           const double* su, const double* pu) {
+                           const double* su, const double* pu, int k_hi) {
     if (m <= 0) return;
     const LpTab T{tabs, coefs, use_tab};
     k_local_solve<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
                                                              counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu);
-    if (slab)   // some neighbourhood is larger than the LDS limit
+    if (slab && k_hi > LP_KL)   // some neighbourhood is larger than the LDS limit
         k_local_solve_big<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z,
                                                                      L, counts, slab_off, slab, c0var, pred, err,
-                                                                     p_base, T, su, pu);
+                                                                     p_base, T, su, pu, k_hi);
+}
+
+// ---------------------------------------------------------------------------------------
+// tiled path (ck_internal.h: CkLocalSys; the factorisation steps are in ck_la.hip)
+// ---------------------------------------------------------------------------------------
+// neighbour list and the padded local system of every system of a batch, one workgroup per system
+__global__ __launch_bounds__(LP_TPB) void k_local_assemble_t(const CkMatern* __restrict__ blk, int metric, int i_pred, int cv,
+                                                              double max_dist, const double* __restrict__ pc, long mpad,
+                                                              const double* __restrict__ sc, const double* __restrict__ z,
+                                                              CkLayout L, const CkLocalSys* __restrict__ sys,
+                                                              double* __restrict__ slab, LpTab T,
+                                                              const double* __restrict__ su,
+                                                              const double* __restrict__ pu) {
+    __shared__ int wsum[LP_TPB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const CkLocalSys q = sys[blockIdx.x];
+    const long p = q.p;
+    const int k = q.k, kq = q.kq;
+    const long ld = q.ld;
+    const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
+    const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
+    const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;
+    const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
+    double* S = slab + q.off;
+    int* idx = reinterpret_cast<int*>(S + (long)CK_LT_ROWS(kq) * ld + 64 * 64);
+    int base = 0;
+    for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {   // ordered compaction, as in k_local_solve
+        const long g = g0 + tid;
+        const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
+        const unsigned long long bal = __ballot(f);
+        const int below = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < wv; ++w2) off += wsum[w2];
+        if (f) idx[off + below] = (int)g;
+        int tot = 0;
+        for (int w2 = 0; w2 < LP_TPB / 64; ++w2) tot += wsum[w2];
+        base += tot;
+        __syncthreads();
+    }
+    // rows [0, kq): the lower triangle, and zeros up to the end of the row's 4-column diagonal block (the
+    // 64 x 64 factorisation loads whole 4 x 4 register blocks); rows [k, kq) are identity padding
+    for (int a = 0; a < kq; ++a) {
+        const int bend = a | 3;
+        if (a < k) {
+            const long ga = idx[a];
+            const int pa = ga >= L.n0p;
+            const double a0 = s0[ga], a1 = s1[ga], a2 = s2[ga], au0 = u0[ga], au1 = u1[ga], au2 = u2[ga];
+            for (int b = tid; b <= bend; b += LP_TPB) {
+                double v = 0.0;
+                if (b <= a) {
+                    const long gb = idx[b];
+                    const int pb = gb >= L.n0p;
+                    v = lp_cov(blk, T, pa + pb, pa == pb, metric, a0, a1, a2, au0, au1, au2, s0[gb], s1[gb], s2[gb], u0[gb],
+                               u1[gb], u2[gb]);
+                }
+                S[(long)a * ld + b] = v;
+            }
+        } else {
+            for (int b = tid; b <= bend; b += LP_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
+        }
+    }
+    for (int a = tid; a < kq; a += LP_TPB) {   // rows kq (c) and kq + 1 (z)
+        double cv0 = 0.0, zv = 0.0;
+        if (a < k) {
+            const long ga = idx[a];
+            const int pa = ga >= L.n0p;
+            cv0 = lp_cov(blk, T, i_pred + pa, pa == i_pred, metric, p0, p1, p2, q0, q1, q2, s0[ga], s1[ga], s2[ga], u0[ga],
+                         u1[ga], u2[ga]);   // point_prediction.py:115-125
+            zv = z[ga];
+        }
+        S[(long)kq * ld + a] = cv0;
+        S[(long)(kq + 1) * ld + a] = zv;
+    }
+}
+
+// pred = v . y, var = c0 - v . v from the two solved rows
+__global__ __launch_bounds__(LP_TPB) void k_local_reduce_t(const CkLocalSys* __restrict__ sys, const double* __restrict__ slab,
+                                                            const long long* __restrict__ info, double c0var,
+                                                            double* __restrict__ pred, double* __restrict__ err) {
+    __shared__ double red[2][LP_TPB];
+    const int tid = threadIdx.x;
+    const CkLocalSys q = sys[blockIdx.x];
+    if (info[blockIdx.x] != 0) {   // src/point_prediction.py:218-222
+        if (tid == 0) {
+            pred[q.p] = NAN;
+            err[q.p] = NAN;
+        }
+        return;
+    }
+    const double* v = slab + q.off + (long)q.kq * q.ld;
+    const double* y = v + q.ld;
+    double s1v = 0.0, s2v = 0.0;
+    for (int a = tid; a < q.k; a += LP_TPB) {
+        s1v += v[a] * y[a];
+        s2v += v[a] * v[a];
+    }
+    red[0][tid] = s1v;
+    red[1][tid] = s2v;
+    __syncthreads();
+    for (int s = LP_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pred[q.p] = red[0][0];
+        const double sd = sqrt(c0var - red[1][0]);
+        err[q.p] = (sd == sd) ? fmax(sd, 0.0) : 0.0;   // np.nanmax([std, 0.0]), point_prediction.py:217
+    }
+}
+
+void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
+                                const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
+                                const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
+                                const double* const* coefs, int use_tab, const double* su, const double* pu) {
+    if (n_sys <= 0) return;
+    const LpTab T{tabs, coefs, use_tab};
+    k_local_assemble_t<<<dim3((unsigned)n_sys), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
+                                                                      sys, slab, T, su, pu);
+}
+
+void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,
+                              const long long* info, double c0var, double* pred, double* err) {
+    if (n_sys <= 0) return;
+    k_local_reduce_t<<<dim3((unsigned)n_sys), dim3(LP_TPB), 0, s>>>(sys, slab, info, c0var, pred, err);
 }
 
 int ck_local_lds_limit() { return LP_KL; }

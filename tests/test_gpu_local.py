@@ -48,9 +48,15 @@ def test_local_cross_validation_rule(tag):
     np.testing.assert_allclose(err ** 2, g[f"cv_pred_err_{tag}"] ** 2, rtol=1e-8, atol=1e-11)
 
 
-def test_local_large_neighbourhood_matches_joint():
+# "local_tile_min": neighbourhoods above it take the tiled path (batched 64-column steps on the MFMA tiles),
+# those below it (and above the LDS limit) the one-workgroup-per-point slab kernel
+TILE_MIN = [0, 256, 10 ** 6]
+
+
+@pytest.mark.parametrize("tile_min", TILE_MIN)
+def test_local_large_neighbourhood_matches_joint(tile_min):
     """max_dist = infinity makes every neighbourhood the whole data set (k = 400 > the LDS limit,
-    global-scratch path): the local predictor must then equal the joint one."""
+    global-scratch paths): the local predictor must then equal the joint one."""
     from sif_xco2_cokriging_amd import native
     g = load_golden("joint_solve")
     pv = g["params_A"]
@@ -59,6 +65,7 @@ def test_local_large_neighbourhood_matches_joint():
     h.set_metric(0)
     h.set_data(0, g["coords0_A"], g["values0_A"])
     h.set_data(1, g["coords1_A"], g["values1_A"])
+    h.set_option("local_tile_min", tile_min)
     pred, err, info = h.predict_local(1, g["pcoords_A"], max_dist=1e9)
     assert info["k_max"] == 400 and info["n_empty"] == 0 and info["n_not_pd"] == 0
     ref = g["pred_A_1"]
@@ -66,8 +73,9 @@ def test_local_large_neighbourhood_matches_joint():
     assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-9
 
 
-def test_local_large_neighbourhood_not_positive_definite():
-    """The blocked large-neighbourhood path (k = 520 > the LDS limit) on an indefinite model: every
+@pytest.mark.parametrize("tile_min", TILE_MIN)
+def test_local_large_neighbourhood_not_positive_definite(tile_min):
+    """The large-neighbourhood paths (k = 520 > the LDS limit) on an indefinite model: every
     local system fails like the joint one does -> (NaN, NaN) per point (src/point_prediction.py:218-222)."""
     from sif_xco2_cokriging_amd import native
     g = load_golden("joint_not_pd")
@@ -78,14 +86,16 @@ def test_local_large_neighbourhood_not_positive_definite():
     h.set_data(0, g["coords0"], np.zeros(260))
     h.set_data(1, g["coords1"], np.zeros(260))
     pc = g["coords0"][:7] + 0.013
+    h.set_option("local_tile_min", tile_min)
     pred, err, info = h.predict_local(0, pc, max_dist=1e9)
     assert info["k_max"] == 520 and info["n_not_pd"] == 7
     assert np.all(np.isnan(pred)) and np.all(np.isnan(err))
 
 
-def test_local_mid_sized_neighbourhoods_vs_oracle():
-    """Neighbourhoods of a few hundred sites (blocked path, sizes that are not multiples of the 32-column
-    block or the 64-row tile) against the oracle's per-point solves."""
+@pytest.mark.parametrize("tile_min,group", [(0, 1), (0, 2), (0, 4), (256, 3), (10 ** 6, 4)])
+def test_local_mid_sized_neighbourhoods_vs_oracle(tile_min, group):
+    """Neighbourhoods of a few hundred sites (sizes that are not multiples of the column blocks or the
+    tiles; a mix of the three size classes) against the oracle's per-point solves."""
     from sif_xco2_cokriging_amd import native, synth
     from oracle import cokrige_oracle as orc
     pb = synth.conus_problem(1500, seed=9)
@@ -96,6 +106,8 @@ def test_local_mid_sized_neighbourhoods_vs_oracle():
     for k in range(2):
         h.set_data(k, pb["coords"][k], pb["values"][k])
     pc = pb["pcoords"][::173][:40]
+    h.set_option("local_tile_min", tile_min)
+    h.set_option("local_group", group)   # 64-column blocks per trailing update of the tiled path
     pred, err, info = h.predict_local(0, pc, max_dist=900.0)
     assert info["k_max"] > 300
     h.set_option("local_slab_mb", 3)   # force several point batches through one small scratch slab
