@@ -132,6 +132,9 @@ struct ck_handle {
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     int local_tile_min = 256;    // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
+    double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
+    double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
+    long long local_slab_doubles = 0; // costs up to seconds, erratically); grows when a call needs more
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
@@ -205,6 +208,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_info);
     if (h->d_tile0) (void)hipFree(h->d_tile0);
+    if (h->local_slab) (void)hipFree(h->local_slab);
     if (h->d_panel_of) (void)hipFree(h->d_panel_of);
     if (h->wl.items) (void)hipFree(h->wl.items);
     if (h->wl.count) (void)hipFree(h->wl.count);
@@ -464,6 +468,11 @@ static int ensure_layout(ck_handle* h) {
     HIPCHK(hipMemcpyAsync(d_tmp, hc.data(), 2 * Np * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->z, hz.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, d_tmp, Np, h->metric, h->s0, h->s1, h->s2, h->su);
+    if (!h->d_chunkb) {   // outside the arena: not part of ck_estimate_bytes
+        HIPCHK(hipMalloc((void**)&h->d_chunkb, (size_t)(4 * ((h->nend + 255) / 256 + 1) * 8)));
+        h->owned.push_back(h->d_chunkb);
+    }
+    ck_launch_local_chunk_bounds(h->stream, h->su, CkLayout{h->n[0], h->n0p, h->nend, h->Npad}, h->d_chunkb);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d_tmp));
     // squared bounding-box diagonal of the data sites (Euclidean table range)
@@ -1187,7 +1196,16 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     HIPCHK(hipMemcpyAsync(d_pc, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, d_pc, mp, h->metric, d_p3, d_p3 + mp, d_p3 + 2 * mp, d_pu);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    ck_launch_local_count(h->stream, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, layout_of(h), d_cnt);
+    // largest chord (in the space of su / pu) a neighbour can have, with a margin (ck_local.hip: LpSearch)
+    double cmax = max_dist;
+    if (h->metric == CK_METRIC_HAVERSINE) {
+        const double half = max_dist / (2.0 * CK_EARTH_RADIUS_KM);
+        cmax = half >= 1.5 ? 4.0 : 2.0 * sin(half);   // beyond ~ a quarter of the globe: no culling
+    }
+    cmax = cmax * (1.0 + 1e-9) + 1e-12;
+    if (!(cmax == cmax)) cmax = INFINITY;
+    ck_launch_local_count(h->stream, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, layout_of(h), d_cnt,
+                          h->d_chunkb, cmax, d_pu);
     HIPCHK(hipGetLastError());
     std::vector<int> cnt(m);
     HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1220,6 +1238,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     }
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+    mem_free += (size_t)h->local_slab_doubles * 8;   // the slab kept from an earlier call is ours to reuse
     long long budget = (long long)std::min<size_t>(mem_free / 4, (size_t)32 << 30) / 8;   // doubles
     if (h->local_slab_mb > 0) budget = (long long)h->local_slab_mb * (1 << 20) / 8;      // option "local_slab_mb" (tests)
     if (budget < need_max) budget = need_max;
@@ -1266,14 +1285,21 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             slab_doubles = acc > slab_doubles ? acc : slab_doubles;
         }
     }
-    if (slab_doubles > 0) HIPCHK(hipMalloc((void**)&d_slab, (size_t)slab_doubles * 8));
+    if (slab_doubles > h->local_slab_doubles) {
+        if (h->local_slab) (void)hipFree(h->local_slab);
+        h->local_slab = nullptr;
+        h->local_slab_doubles = 0;
+        HIPCHK(hipMalloc((void**)&h->local_slab, (size_t)slab_doubles * 8));
+        h->local_slab_doubles = slab_doubles;
+    }
+    if (slab_doubles > 0) d_slab = h->local_slab;
     HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
     const int use_tab = tables_usable(h) ? 1 : 0;
     for (const auto& bt : batches)
         ck_launch_local_solve(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, bt.first, bt.second - bt.first,
                               mp, h->s0, h->z, layout_of(h), d_cnt, d_off, d_slab, c0var, d_out, d_out + mp, h->d_tabs,
-                              h->d_coefptr, use_tab, h->su, d_pu, k_hi);
+                              h->d_coefptr, use_tab, h->su, d_pu, k_hi, h->d_chunkb, cmax);
     HIPCHK(hipGetLastError());
     if (!tiled.empty()) {
         HIPCHK(hipMalloc((void**)&d_sys, sysv.size() * sizeof(CkLocalSys)));
@@ -1284,7 +1310,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             const CkLocalSys* bsys = d_sys + tb.first;
             const int nb = (int)(tb.second - tb.first);
             ck_launch_local_assemble_t(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, mp, h->s0, h->z,
-                                       layout_of(h), bsys, nb, d_slab, h->d_tabs, h->d_coefptr, use_tab, h->su, d_pu);
+                                       layout_of(h), bsys, nb, d_slab, h->d_tabs, h->d_coefptr, use_tab, h->su, d_pu,
+                                       h->d_chunkb, cmax);
             const int kq_max = sysv[tb.first].kq;
             int na = nb;
             const int G = h->local_group;
@@ -1320,7 +1347,6 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     (void)hipFree(d_out);
     (void)hipFree(d_cnt);
     (void)hipFree(d_off);
-    if (d_slab) (void)hipFree(d_slab);
     if (d_sys) (void)hipFree(d_sys);
     if (d_linfo) (void)hipFree(d_linfo);
     return 0;

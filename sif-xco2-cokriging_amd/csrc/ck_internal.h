@@ -123,15 +123,19 @@ void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int cova
 
 // ---- local-neighbourhood cokriging (ck_local.hip) -------------------------------------------
 // pc: 3 x mpad prediction-site coordinates, sc: 3 x npad site coordinates (exact-formula form)
+// cb: chunk bounds of the sites (ck_launch_local_chunk_bounds: 4 x ceil(nend / 256) doubles), cmax: largest chord
+// (distance in the space of the chord vectors su / pu) a neighbour can have, with its safety margin
+void ck_launch_local_chunk_bounds(hipStream_t s, const double* su, CkLayout L, double* cb);
 void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double max_dist, const double* pc,
-                           int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts);
+                           int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts, const double* cb,
+                           double cmax, const double* pu);
 // slab_off[p]: offset (doubles) of point p's scratch slab ((k + 2) k doubles + k ints) when its
 // neighbourhood exceeds the LDS limit
 void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
                            double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
-                           const double* su, const double* pu, int k_hi);
+                           const double* su, const double* pu, int k_hi, const double* cb, double cmax);
 int ck_local_lds_limit();
 
 // Large neighbourhoods (k > k_hi above): the "tiled" path.  The systems of a batch are factored TOGETHER,
@@ -156,7 +160,8 @@ static inline long long ck_local_tiled_doubles(long long k) {
 void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                                 const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
                                 const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
-                                const double* const* coefs, int use_tab, const double* su, const double* pu);
+                                const double* const* coefs, int use_tab, const double* su, const double* pu,
+                                const double* cb, double cmax);
 // Columns are processed in groups of g 64-column blocks [g0, g0 + 64 g): block i of a group first receives the
 // updates of the group's earlier blocks (one pass, K = 64 i), then its diagonal block is factored and inverted and
 // the rows below are solved; the trailing matrix behind the group is updated once with K = 64 g (a g-th of the

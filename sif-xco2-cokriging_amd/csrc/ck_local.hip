@@ -57,18 +57,85 @@ __device__ __forceinline__ double lp_cov(const CkMatern* blk, const LpTab& T, in
     return ck_cov_entry(blk[bidx], lp_dist(metric, a0, a1, a2, b0, b1, b2), nug);
 }
 
+// Radius search with chunk culling: the sites are laid out along a Hilbert curve (ck_api.hip: site_order), so
+// 256 consecutive sites are a compact patch.  Per chunk: the mean c of its chord vectors and rad = max |u - c|.
+// A site can only be within max_dist of a point with chord vector q if its chord to q is <= cmax (haversine:
+// 2 sin(max_dist / 2R), monotone; Euclid: max_dist), and |u - q| >= |c - q| - rad, so a chunk with
+// |c - q| - rad > cmax holds no neighbour and is skipped by the whole workgroup.  cmax carries a relative
+// margin of 1e-9 (host), far above the rounding of either formula; which sites pass is still decided by the
+// reference's distance formula, so the neighbour lists do not change.
+struct LpSearch {
+    const double* cb;   // 4 x nchunk: centre x, y, z, rad (rad < 0: no valid site in the chunk)
+    long nchunk;
+    double cmax;
+};
+
+__device__ __forceinline__ bool lp_chunk_far(const LpSearch& R, long chunk, double q0, double q1, double q2) {
+    if (chunk >= R.nchunk) return true;
+    const double rad = R.cb[3 * R.nchunk + chunk];
+    if (rad < 0.0) return true;
+    const double dx = R.cb[chunk] - q0, dy = R.cb[R.nchunk + chunk] - q1, dz = R.cb[2 * R.nchunk + chunk] - q2;
+    return sqrt(dx * dx + dy * dy + dz * dz) - rad > R.cmax;
+}
+
+__global__ __launch_bounds__(LP_TPB) void k_local_chunk_bounds(const double* __restrict__ su, CkLayout L, long nchunk,
+                                                                double* __restrict__ cb) {
+    __shared__ double red[4][LP_TPB];
+    const int tid = threadIdx.x;
+    const long g = (long)blockIdx.x * LP_TPB + tid;
+    const bool valid = g < L.n0 || (g >= L.n0p && g < L.nend);
+    const double x = valid ? su[g] : 0.0, y = valid ? su[L.npad + g] : 0.0, zc = valid ? su[2 * L.npad + g] : 0.0;
+    red[0][tid] = x;
+    red[1][tid] = y;
+    red[2][tid] = zc;
+    red[3][tid] = valid ? 1.0 : 0.0;
+    __syncthreads();
+    for (int s = LP_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s)
+            for (int c = 0; c < 4; ++c) red[c][tid] += red[c][tid + s];
+        __syncthreads();
+    }
+    const double n = red[3][0];
+    const double cx = n > 0.0 ? red[0][0] / n : 0.0, cy = n > 0.0 ? red[1][0] / n : 0.0, cz = n > 0.0 ? red[2][0] / n : 0.0;
+    __syncthreads();
+    const double dx = x - cx, dy = y - cy, dz = zc - cz;
+    red[0][tid] = valid ? sqrt(dx * dx + dy * dy + dz * dz) : 0.0;
+    __syncthreads();
+    for (int s = LP_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) red[0][tid] = fmax(red[0][tid], red[0][tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        cb[blockIdx.x] = cx;
+        cb[nchunk + blockIdx.x] = cy;
+        cb[2 * nchunk + blockIdx.x] = cz;
+        cb[3 * nchunk + blockIdx.x] = n > 0.0 ? red[0][0] * (1.0 + 1e-12) : -1.0;
+    }
+}
+
+void ck_launch_local_chunk_bounds(hipStream_t s, const double* su, CkLayout L, double* cb) {
+    const long nchunk = (L.nend + LP_TPB - 1) / LP_TPB;
+    if (nchunk <= 0) return;
+    k_local_chunk_bounds<<<dim3((unsigned)nchunk), dim3(LP_TPB), 0, s>>>(su, L, nchunk, cb);
+}
+
 // neighbour count per prediction point
 __global__ __launch_bounds__(LP_TPB) void k_local_count(int metric, int i_pred, int cv, double max_dist,
                                                          const double* __restrict__ pc, long mpad,
                                                          const double* __restrict__ sc, CkLayout L,
-                                                         int* __restrict__ counts) {
+                                                         int* __restrict__ counts, LpSearch R,
+                                                         const double* __restrict__ pu) {
     __shared__ int red[LP_TPB];
     const long p = blockIdx.x;
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
+    const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
     int c = 0;
-    for (long g = threadIdx.x; g < L.nend; g += LP_TPB)
-        c += lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2) ? 1 : 0;
+    for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {
+        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2)) continue;
+        const long g = g0 + threadIdx.x;
+        c += (g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2)) ? 1 : 0;
+    }
     red[threadIdx.x] = c;
     __syncthreads();
     for (int s = LP_TPB / 2; s > 0; s >>= 1) {
@@ -87,7 +154,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
                                                          double* __restrict__ slab, double c0var,
                                                          double* __restrict__ pred, double* __restrict__ err,
                                                          long p_base, LpTab T, const double* __restrict__ su,
-                                                         const double* __restrict__ pu) {
+                                                         const double* __restrict__ pu, LpSearch R) {
     __shared__ double lS[(LP_KL + 2) * LP_KL];
     __shared__ int lidx[LP_KL];
     __shared__ int wsum[LP_TPB / 64];
@@ -116,6 +183,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
     if (tid == 0) fail = 0;
     int base = 0;
     for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {
+        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2)) continue;   // uniform
         const long g = g0 + tid;
         const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
         const unsigned long long bal = __ballot(f);
@@ -227,7 +295,7 @@ __global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* _
                                                              double* __restrict__ slab, double c0var,
                                                              double* __restrict__ pred, double* __restrict__ err,
                                                              long p_base, LpTab T, const double* __restrict__ su,
-                                                             const double* __restrict__ pu, int k_hi) {
+                                                             const double* __restrict__ pu, int k_hi, LpSearch R) {
     __shared__ __attribute__((aligned(16))) double lbuf[2 * LB_IB * (64 + 4)];
     double (*At)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf);                 // At[c][r] = strip of the tile's rows
     double (*Bt)[64 + 4] = reinterpret_cast<double (*)[64 + 4]>(lbuf + LB_IB * (64 + 4));   // Bt[c][r] = ... columns
@@ -252,6 +320,7 @@ __global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* _
     if (tid == 0) fail = 0;
     int base = 0;
     for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {
+        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2)) continue;   // uniform
         const long g = g0 + tid;
         const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
         const unsigned long long bal = __ballot(f);
@@ -426,9 +495,11 @@ __global__ __launch_bounds__(LP_TPB, 3) void k_local_solve_big(const CkMatern* _
 }
 
 void ck_launch_local_count(hipStream_t s, int metric, int i_pred, int cv, double max_dist, const double* pc,
-                           int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts) {
+                           int64_t m, int64_t mpad, const double* sc, CkLayout L, int* counts, const double* cb,
+                           double cmax, const double* pu) {
     if (m <= 0) return;
-    k_local_count<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(metric, i_pred, cv, max_dist, pc, mpad, sc, L, counts);
+    const LpSearch R{cb, (long)((L.nend + LP_TPB - 1) / LP_TPB), cmax};
+    k_local_count<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(metric, i_pred, cv, max_dist, pc, mpad, sc, L, counts, R, pu);
 }
 
 // points [p_base, p_base + m): slab_off is relative to `slab` within this batch (ck_predict_local)
@@ -436,29 +507,46 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
                            const double* pc, int64_t p_base, int64_t m, int64_t mpad, const double* sc, const double* z,
                            CkLayout L, const int* counts, const long long* slab_off, double* slab, double c0var,
                            double* pred, double* err, const CkTable* tabs, const double* const* coefs, int use_tab,
-                           const double* su, const double* pu, int k_hi) {
+                           const double* su, const double* pu, int k_hi, const double* cb, double cmax) {
     if (m <= 0) return;
     const LpTab T{tabs, coefs, use_tab};
+    const LpSearch R{cb, (long)((L.nend + LP_TPB - 1) / LP_TPB), cmax};
     k_local_solve<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                             counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu);
+                                                             counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu, R);
     if (slab && k_hi > LP_KL)   // some neighbourhood is larger than the LDS limit
         k_local_solve_big<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z,
                                                                      L, counts, slab_off, slab, c0var, pred, err,
-                                                                     p_base, T, su, pu, k_hi);
+                                                                     p_base, T, su, pu, k_hi, R);
 }
 
 // ---------------------------------------------------------------------------------------
 // tiled path (ck_internal.h: CkLocalSys; the factorisation steps are in ck_la.hip)
 // ---------------------------------------------------------------------------------------
-// neighbour list and the padded local system of every system of a batch, one workgroup per system
-__global__ __launch_bounds__(LP_TPB) void k_local_assemble_t(const CkMatern* __restrict__ blk, int metric, int i_pred, int cv,
-                                                              double max_dist, const double* __restrict__ pc, long mpad,
-                                                              const double* __restrict__ sc, const double* __restrict__ z,
-                                                              CkLayout L, const CkLocalSys* __restrict__ sys,
-                                                              double* __restrict__ slab, LpTab T,
-                                                              const double* __restrict__ su,
-                                                              const double* __restrict__ pu) {
-    __shared__ int wsum[LP_TPB / 64];
+// neighbour list and the padded local system of every system of a batch, one workgroup per system.
+// The neighbours come out sorted by process (process 0 first), so the lower triangle splits into three
+// regions with ONE Matern block each -- (0,0), (1,0) and (1,1) -- and a region is assembled with its table in
+// LDS, like the joint assembly (ck_cov.hip): chord vectors of LT_BC columns and LT_AC rows staged in LDS, a
+// thread takes one column of four rows at a time (four independent Horner chains), writes run along rows.
+// Entries outside the table (the diagonal, coincident sites, pairs beyond its range) and everything when the
+// tables are off go through the exact evaluator in a second, rolled loop.
+#ifndef LT_ABL
+#define LT_ABL 0
+#endif
+#define LT_BC 1024
+#define LT_AC 256
+#define LT_TPB 512   // 8 waves: with two workgroups per CU (LDS) four waves per SIMD hide the table-read latency
+__global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* __restrict__ blk, int metric, int i_pred,
+                                                                 int cv, double max_dist, const double* __restrict__ pc,
+                                                                 long mpad, const double* __restrict__ sc,
+                                                                 const double* __restrict__ z, CkLayout L,
+                                                                 const CkLocalSys* __restrict__ sys,
+                                                                 double* __restrict__ slab, LpTab T,
+                                                                 const double* __restrict__ su,
+                                                                 const double* __restrict__ pu, LpSearch R) {
+    __shared__ double tab[(CK_TAB_DEG + 1) * CK_TAB_STRIDE];
+    __shared__ double bu[3][LT_BC];
+    __shared__ double au[3][LT_AC];
+    __shared__ int wsum[LT_TPB / 64], wsum0[LT_TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const CkLocalSys q = sys[blockIdx.x];
     const long p = q.p;
@@ -470,45 +558,145 @@ __global__ __launch_bounds__(LP_TPB) void k_local_assemble_t(const CkMatern* __r
     const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
     double* S = slab + q.off;
     int* idx = reinterpret_cast<int*>(S + (long)CK_LT_ROWS(kq) * ld + 64 * 64);
-    int base = 0;
-    for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {   // ordered compaction, as in k_local_solve
+    int base = 0, k0 = 0;   // k0: neighbours of process 0
+    for (long g0 = 0; g0 < L.nend; g0 += LT_TPB) {   // ordered compaction, as in k_local_solve
+        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2) && lp_chunk_far(R, g0 / LP_TPB + 1, q0, q1, q2)) continue;   // uniform
         const long g = g0 + tid;
         const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
-        const unsigned long long bal = __ballot(f);
+        const unsigned long long bal = __ballot(f), bal0 = __ballot(f && g < L.n0p);
         const int below = __popcll(bal & ((1ULL << lane) - 1ULL));
-        if (lane == 0) wsum[wv] = __popcll(bal);
+        if (lane == 0) {
+            wsum[wv] = __popcll(bal);
+            wsum0[wv] = __popcll(bal0);
+        }
         __syncthreads();
         int off = base;
         for (int w2 = 0; w2 < wv; ++w2) off += wsum[w2];
         if (f) idx[off + below] = (int)g;
-        int tot = 0;
-        for (int w2 = 0; w2 < LP_TPB / 64; ++w2) tot += wsum[w2];
-        base += tot;
+        for (int w2 = 0; w2 < LT_TPB / 64; ++w2) {
+            base += wsum[w2];
+            k0 += wsum0[w2];
+        }
         __syncthreads();
     }
-    // rows [0, kq): the lower triangle, and zeros up to the end of the row's 4-column diagonal block (the
-    // 64 x 64 factorisation loads whole 4 x 4 register blocks); rows [k, kq) are identity padding
-    for (int a = 0; a < kq; ++a) {
-        const int bend = a | 3;
-        if (a < k) {
-            const long ga = idx[a];
-            const int pa = ga >= L.n0p;
-            const double a0 = s0[ga], a1 = s1[ga], a2 = s2[ga], au0 = u0[ga], au1 = u1[ga], au2 = u2[ga];
-            for (int b = tid; b <= bend; b += LP_TPB) {
-                double v = 0.0;
-                if (b <= a) {
-                    const long gb = idx[b];
-                    const int pb = gb >= L.n0p;
-                    v = lp_cov(blk, T, pa + pb, pa == pb, metric, a0, a1, a2, au0, au1, au2, s0[gb], s1[gb], s2[gb], u0[gb],
-                               u1[gb], u2[gb]);
-                }
-                S[(long)a * ld + b] = v;
+#if LT_ABL == 1
+    for (int reg = 0; reg < 0; ++reg) {
+#else
+    for (int reg = 0; reg < 3; ++reg) {
+#endif
+        const int alo = reg == 0 ? 0 : k0, ahi = reg == 0 ? k0 : k;
+        const int blo = reg == 2 ? k0 : 0, bhi = reg == 2 ? k : k0;
+        if (alo >= ahi || blo >= bhi) continue;   // uniform
+        const int nug = reg != 1;
+        const double cdiag = blk[reg].amp + blk[reg].nugget;   // an entry's own site: h = 0 (ck_cov_entry)
+        int tbase = 0, tn = 0;                    // tn = 0: every entry takes the exact evaluator
+        __syncthreads();
+        if (T.use) {
+            tbase = T.tabs[reg].base;
+            tn = T.tabs[reg].n_int;
+            const double* cf = T.coefs[reg];
+            for (int e = tid; e < (CK_TAB_DEG + 1) * tn; e += LT_TPB) {
+                const int kk = e / tn, iv = e - kk * tn;
+                tab[kk * CK_TAB_STRIDE + iv] = cf[kk * CK_TAB_STRIDE + iv];
             }
-        } else {
-            for (int b = tid; b <= bend; b += LP_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
+        }
+        for (int bc = blo; bc < bhi; bc += LT_BC) {
+            const int nbc = min(LT_BC, bhi - bc);
+            __syncthreads();
+            for (int e = tid; e < nbc; e += LT_TPB) {
+                const long g = idx[bc + e];
+                bu[0][e] = u0[g];
+                bu[1][e] = u1[g];
+                bu[2][e] = u2[g];
+            }
+            for (int ac = max(alo, bc); ac < ahi; ac += LT_AC) {
+                const int nac = min(LT_AC, ahi - ac);
+                __syncthreads();
+                if (tid < nac) {
+                    const long g = idx[ac + tid];
+                    au[0][tid] = u0[g];
+                    au[1][tid] = u1[g];
+                    au[2][tid] = u2[g];
+                }
+                __syncthreads();
+                for (int r0 = 0; r0 < nac; r0 += 4) {
+                    const int nr = min(4, nac - r0), amax = ac + r0 + nr - 1;
+                    for (int bl = tid; bl < nbc && bc + bl <= amax; bl += LT_TPB) {
+                        const int b = bc + bl;
+                        const double b0 = bu[0][bl], b1 = bu[1][bl], b2 = bu[2][bl];
+                        // four rows of this column at once: chords / interval indices, then all 32 coefficient
+                        // reads, then four interleaved Horner chains (the barriers keep hipcc from sinking every
+                        // read next to its FMA -- one exposed LDS latency per Horner step otherwise)
+                        unsigned need = 0, fast = 0;
+                        double y[4], cf[CK_TAB_DEG + 1][4];
+                        const double* lp[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rr = min(r0 + r, nac - 1);
+                            const int a = ac + r0 + r;
+                            const double dx = au[0][rr] - b0, dy = au[1][rr] - b1, dz = au[2][rr] - b2;
+                            int iv;
+                            y[r] = ck_table_y(dx * dx + dy * dy + dz * dz, &iv, tbase);
+                            const bool in = r < nr && b <= a, hit = (unsigned)iv < (unsigned)tn;
+                            fast |= (in && hit) ? 1u << r : 0u;
+                            need |= (in && !hit) ? 1u << r : 0u;
+                            lp[r] = tab + min(max(iv, 0), max(tn - 1, 0));   // keep the lookup inside the table
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = CK_TAB_DEG; kk >= 0; --kk)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cf[kk][r] = lp[r][kk * CK_TAB_STRIDE];
+                        __builtin_amdgcn_sched_barrier(0);
+                        double pv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = cf[CK_TAB_DEG][r];
+#pragma unroll
+                        for (int kk = CK_TAB_DEG - 1; kk >= 0; --kk)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pv[r] = fma(pv[r], y[r], cf[kk][r]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int a = ac + r0 + r;
+#if LT_ABL == 2
+                            if ((fast >> r & 1u) && pv[r] != pv[r])
+#else
+                            if (fast >> r & 1u)
+#endif
+                                S[(long)a * ld + b] = pv[r];
+                            else if ((need >> r & 1u) && b == a) {   // one per row: kept out of the slow loop below
+                                S[(long)a * ld + b] = cdiag;
+                                need &= ~(1u << r);
+                            }
+                        }
+#if LT_ABL == 3
+                        if (need && ld < 0) {
+#else
+                        if (need) {
+#endif
+                            const long gb = idx[b];
+                            const double e0 = s0[gb], e1 = s1[gb], e2 = s2[gb];
+#pragma unroll 1
+                            for (int r = 0; r < 4; ++r)
+                                if (need >> r & 1u) {
+                                    const int a = ac + r0 + r;
+                                    const long ga = idx[a];
+                                    S[(long)a * ld + b] =
+                                        ck_cov_entry(blk[reg], lp_dist(metric, s0[ga], s1[ga], s2[ga], e0, e1, e2), nug);
+                                }
+                        }
+                    }
+                }
+            }
         }
     }
-    for (int a = tid; a < kq; a += LP_TPB) {   // rows kq (c) and kq + 1 (z)
+    // zeros up to the end of each row's 4-column diagonal block (the 64 x 64 factorisation loads whole 4 x 4
+    // register blocks); rows [k, kq): identity padding
+    for (int a = tid; a < k; a += LT_TPB)
+        for (int b = a + 1; b <= (a | 3); ++b) S[(long)a * ld + b] = 0.0;
+    for (int a = k; a < kq; ++a)
+        for (int b = tid; b <= (a | 3); b += LT_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
+    for (int a = tid; a < kq; a += LT_TPB) {   // rows kq (c) and kq + 1 (z)
         double cv0 = 0.0, zv = 0.0;
         if (a < k) {
             const long ga = idx[a];
@@ -563,11 +751,13 @@ __global__ __launch_bounds__(LP_TPB) void k_local_reduce_t(const CkLocalSys* __r
 void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                                 const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
                                 const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
-                                const double* const* coefs, int use_tab, const double* su, const double* pu) {
+                                const double* const* coefs, int use_tab, const double* su, const double* pu,
+                                const double* cb, double cmax) {
     if (n_sys <= 0) return;
     const LpTab T{tabs, coefs, use_tab};
-    k_local_assemble_t<<<dim3((unsigned)n_sys), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                                      sys, slab, T, su, pu);
+    const LpSearch R{cb, (long)((L.nend + LP_TPB - 1) / LP_TPB), cmax};
+    k_local_assemble_t<<<dim3((unsigned)n_sys), dim3(LT_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
+                                                                      sys, slab, T, su, pu, R);
 }
 
 void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,

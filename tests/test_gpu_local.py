@@ -118,6 +118,33 @@ def test_local_mid_sized_neighbourhoods_vs_oracle(tile_min, group):
     np.testing.assert_allclose(err ** 2, re ** 2, rtol=1e-8, atol=1e-10)
 
 
+def test_local_radius_search_culling_is_exact():
+    """The radius search skips whole 256-site chunks by a bounding-ball test.  With the sites in Hilbert order
+    (default) almost every chunk is skipped, in the caller's order (site_order = 0) hardly any: neighbour counts,
+    empty neighbourhoods and predictions must agree, also in cross-validation mode (d > 0 rule) and for a
+    radius that reaches across the whole domain."""
+    from sif_xco2_cokriging_amd import native, synth
+    pb = synth.conus_problem(3000, seed=4)
+    pv = pb["params"]
+    pc = np.vstack([pb["pcoords"][::37], pb["coords"][0][:50], [[10.0, -170.0]]])   # grid, data sites, far away
+    out = {}
+    for order in (0, 1):
+        h = native.Handle(0)
+        h.set_option("site_order", order)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(0)
+        for k in range(2):
+            h.set_data(k, pb["coords"][k], pb["values"][k])
+        out[order] = [h.predict_local(0, pc, max_dist=md, cv=cv) for md, cv in ((60.0, False), (150.0, True), (9000.0, False))]
+    for (p0, e0, i0), (p1, e1, i1) in zip(out[0], out[1]):
+        assert i0 == i1
+        assert np.array_equal(np.isnan(p0), np.isnan(p1))
+        np.testing.assert_allclose(p0, p1, rtol=1e-9, atol=1e-11, equal_nan=True)
+        np.testing.assert_allclose(e0 ** 2, e1 ** 2, rtol=1e-9, atol=1e-11, equal_nan=True)   # variances: at a data
+        # site the kriging variance is 0 up to cancellation noise, its square root is not comparable
+    assert out[1][0][2]["n_empty"] >= 1        # the far-away point at 60 km
+
+
 def test_predictor_call_signature_and_warnings():
     import pandas as pd
     P, g = _predictor("A")
