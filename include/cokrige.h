@@ -215,7 +215,10 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
  * ck_factor / ck_predict;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
- * 32 GiB; the points are processed in batches that fit);
+ * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
+ * "local_tile_min" (default 256): neighbourhoods with more sites than this are factored by the tiled path of
+ * ck_predict_local (batched 64-column steps on the matrix cores) instead of one workgroup per point;
+ * "local_group" (1..16, default 4) = 64-column blocks per trailing update of that path;
  * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
  * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,
