@@ -118,6 +118,42 @@ def test_local_mid_sized_neighbourhoods_vs_oracle(tile_min, group):
     np.testing.assert_allclose(err ** 2, re ** 2, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("case", ["euclid", "euclid_cv", "univariate", "haversine_cv_i1"])
+@pytest.mark.parametrize("tile_min", [0, 10 ** 6])
+def test_local_large_paths_variants_vs_oracle(case, tile_min):
+    """The two large-neighbourhood paths on the variants the other tests do not reach: Euclidean metric,
+    cross-validation mode (prediction points = data sites, d > 0 rule for the predicted process only), a
+    univariate model, process 1 as the target."""
+    from sif_xco2_cokriging_amd import native, synth
+    from oracle import cokrige_oracle as orc
+    if case.startswith("euclid"):
+        pb, md = synth.unit_square_problem(450, grid_side=6, seed=31), 0.45
+    else:
+        pb, md = synth.conus_problem(500, seed=32), 1500.0
+    pv = list(pb["params"])
+    cv = case.endswith("cv") or "_cv_" in case
+    i_pred = 1 if case.endswith("i1") else 0
+    coords, values = pb["coords"], pb["values"]
+    h = native.Handle(0)
+    if case == "univariate":
+        coords, values = coords[:1], values[:1]
+        h.set_model(1, pv[0:1], pv[2:3], pv[5:6], pv[8:9])
+        op = orc.Params.from_flat([pv[0], pv[2], pv[5], pv[8]])
+    else:
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        op = orc.Params.from_flat(pv)
+    h.set_metric(pb["metric"])
+    for k in range(len(coords)):
+        h.set_data(k, coords[k], values[k])
+    h.set_option("local_tile_min", tile_min)
+    pc = coords[i_pred][::9] if cv else pb["pcoords"][::211][:36]
+    pred, err, info = h.predict_local(i_pred, pc, max_dist=md, cv=cv)
+    assert info["k_max"] > 124 and info["n_not_pd"] == 0
+    rp, re = orc.local_predict(op, coords, values, pc, i_pred, pb["metric"], md, cv)[:2]
+    np.testing.assert_allclose(pred, rp, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(err ** 2, re ** 2, rtol=1e-8, atol=1e-9)
+
+
 def test_local_radius_search_culling_is_exact():
     """The radius search skips whole 256-site chunks by a bounding-ball test.  With the sites in Hilbert order
     (default) almost every chunk is skipped, in the caller's order (site_order = 0) hardly any: neighbour counts,
