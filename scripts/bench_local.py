@@ -15,6 +15,8 @@ for k in range(2):
     h.set_data(k, pb["coords"][k], pb["values"][k])
 if os.environ.get("CK_LOCAL_TILE_MIN"):   # A/B of the size-class boundary (default 256)
     h.set_option("local_tile_min", int(os.environ["CK_LOCAL_TILE_MIN"]))
+if os.environ.get("CK_LOCAL_SLAB_MB"):
+    h.set_option("local_slab_mb", int(os.environ["CK_LOCAL_SLAB_MB"]))
 if os.environ.get("CK_LOCAL_GROUP"):
     h.set_option("local_group", int(os.environ["CK_LOCAL_GROUP"]))
 out = []

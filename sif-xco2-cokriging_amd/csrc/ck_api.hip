@@ -1276,7 +1276,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
                 b0 = t;
                 acc = 0;
             }
-            const int kq = (int)((k + 63) / 64 * 64);
+            const int kq = (int)ck_local_tiled_kq(k);
             sysv[t] = CkLocalSys{acc, (int)k, kq, kq + 128, (int)tiled[t]};
             acc += nd;
         }

@@ -139,22 +139,27 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
 int ck_local_lds_limit();
 
 // Large neighbourhoods (k > k_hi above): the "tiled" path.  The systems of a batch are factored TOGETHER,
-// 64 columns per step, by three launches per step over all systems that still have columns left (diagonal
-// block + its inverse, row solves, trailing update on 128 x 128 MFMA tiles) -- the tile kernels of the joint
-// path with a system index in blockIdx.y.  A system's scratch (slab + off):
-//   S     CK_LT_ROWS(kq) rows x ld doubles, ld = kq + 128, kq = k rounded up to 64.  Rows/cols [0, k): local
-//         covariance (lower triangle); [k, kq): identity padding; rows kq, kq + 1: the c and z rows, which
-//         ride along as in the other local kernels.  The 128 rows / columns beyond exist only so that whole
-//         tiles can be read and written without bounds checks; nothing valid depends on them.
+// 64 columns per step, by launches over all systems that still have columns left (diagonal block + its
+// inverse, row solves, trailing update on 128 x 128 MFMA tiles) -- the tile kernels of the joint path with a
+// system index in the grid.  A system's scratch (slab + off):
+//   S     CK_LT_ROWS(kq) rows x ld doubles, ld = kq + 128, kq = k + 2 rounded up to 64: ONE padded symmetric
+//         matrix.  Rows/cols [0, k): local covariance (lower triangle); [k, kq - 2): identity padding; rows
+//         kq - 2 and kq - 1: the c and z rows, which ride along as in the other local kernels -- here as two
+//         more matrix rows with a huge diagonal (CK_LT_BIG), so that the Cholesky recurrences themselves do
+//         their forward substitution (L[r][j] = (S[r][j] - sum) / L[j][j]) and never see a bad pivot there.
+//         The 128 rows / columns beyond kq exist only so that whole tiles can be read and written without
+//         bounds checks; nothing valid depends on them.
 //   Linv  64 x 64 doubles (inverse of the current diagonal block)
 //   idx   k ints (neighbour list)
 struct CkLocalSys {
     long long off;      // doubles into the slab
     int k, kq, ld, p;   // neighbours, padded size, leading dimension, prediction point index
 };
-#define CK_LT_ROWS(kq) ((kq) + 130)
+#define CK_LT_BIG 1e200
+#define CK_LT_ROWS(kq) ((kq) + 128)
+static inline long long ck_local_tiled_kq(long long k) { return (k + 2 + 63) / 64 * 64; }
 static inline long long ck_local_tiled_doubles(long long k) {
-    const long long kq = (k + 63) / 64 * 64;
+    const long long kq = ck_local_tiled_kq(k);
     return (CK_LT_ROWS(kq) * (kq + 128) + 64 * 64 + (k + 1) / 2 + 1) & ~1LL;
 }
 void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,

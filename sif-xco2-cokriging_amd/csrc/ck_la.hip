@@ -1250,14 +1250,14 @@ __global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
     const CkLocalSys q = sys[blockIdx.y];
     const int jb = g0 + 64 * i;
-    const int nchunk = (q.kq + 2 - jb - 64 + 63) / 64;   // rows jb + 64 .. kq + 1
+    const int nchunk = (q.kq - jb - 64) / 64;   // rows jb + 64 .. kq - 1
     if ((int)blockIdx.x >= nchunk) return;
     double* S = slab + q.off;
     lt_rows_body<true>(S, q.ld, g0, i, jb + 64 + 64 * (int)blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, As, Bs);
 }
 
-// trailing update behind a group of columns [g0, g0 + K):  C -= A A^T on 128 x 128 tiles, rows g0 + K .. kq + 1,
-// columns g0 + K .. kq - 1, lower tiles only.  All tiles of a system run on one XCD (they share the A rows through
+// trailing update behind a group of columns [g0, g0 + K):  C -= A A^T on 128 x 128 tiles, rows and columns
+// g0 + K .. kq - 1, lower tiles only.  All tiles of a system run on one XCD (they share the A rows through
 // its L2): with workgroups dealt out to the 8 XCDs round-robin by linear id, system y' = 8 (id / (8 GX)) + id % 8.
 __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restrict__ sys, double* __restrict__ slab,
                                                        int g0, int K, int n_active) {
@@ -1268,13 +1268,12 @@ __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restri
     if (y >= n_active) return;
     const CkLocalSys q = sys[y];
     const int o = g0 + K;
-    const int T = (q.kq + 2 - o + 127) / 128, Tc = (q.kq - o + 127) / 128;
+    const int T = (q.kq - o + 127) / 128;
     if (t >= T * (T + 1) / 2) return;
     int tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while (tm * (tm + 1) / 2 > t) --tm;
     while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
     const int tn = t - tm * (tm + 1) / 2;
-    if (tn >= Tc) return;
     double* S = slab + q.off;
     const double* A = S + (long)o * q.ld + g0;
     gemm_tile_e<0>(S + (long)o * q.ld + o, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, K, lds);
@@ -1285,15 +1284,15 @@ void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* s
                                  int kq_max, long long* info) {
     if (n_active <= 0) return;
     k_lt_potrf64<<<dim3((unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, info);
-    const int rows = kq_max + 2 - (g0 + 64 * i) - 64;   // >= 2: the c and z rows
-    k_lt_rows<<<dim3((unsigned)((rows + 63) / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i);
+    const int rows = kq_max - (g0 + 64 * i) - 64;
+    if (rows > 0) k_lt_rows<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i);
 }
 
 // trailing update behind the group [g0, g0 + K) for the first n_active systems (those with kq > g0 + K)
 void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
                                     int kq_max) {
     if (n_active <= 0 || kq_max - g0 - K <= 0) return;
-    const int T = (kq_max + 2 - g0 - K + 127) / 128;
+    const int T = (kq_max - g0 - K + 127) / 128;
     k_lt_update<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)((n_active + 7) / 8 * 8)), dim3(512), 0, s>>>(sys, slab, g0, K,
                                                                                                       n_active);
 }

@@ -691,12 +691,13 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
         }
     }
     // zeros up to the end of each row's 4-column diagonal block (the 64 x 64 factorisation loads whole 4 x 4
-    // register blocks); rows [k, kq): identity padding
+    // register blocks); rows [k, kq - 2): identity padding
     for (int a = tid; a < k; a += LT_TPB)
         for (int b = a + 1; b <= (a | 3); ++b) S[(long)a * ld + b] = 0.0;
-    for (int a = k; a < kq; ++a)
+    for (int a = k; a < kq - 2; ++a)
         for (int b = tid; b <= (a | 3); b += LT_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
-    for (int a = tid; a < kq; a += LT_TPB) {   // rows kq (c) and kq + 1 (z)
+    // rows kq - 2 (c) and kq - 1 (z): two more rows of the matrix, their own 2 x 2 corner diag(BIG, BIG)
+    for (int a = tid; a < kq; a += LT_TPB) {
         double cv0 = 0.0, zv = 0.0;
         if (a < k) {
             const long ga = idx[a];
@@ -705,8 +706,8 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
                          u1[ga], u2[ga]);   // point_prediction.py:115-125
             zv = z[ga];
         }
-        S[(long)kq * ld + a] = cv0;
-        S[(long)(kq + 1) * ld + a] = zv;
+        S[(long)(kq - 2) * ld + a] = a == kq - 2 ? CK_LT_BIG : cv0;
+        S[(long)(kq - 1) * ld + a] = a == kq - 1 ? CK_LT_BIG : zv;
     }
 }
 
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_reduce_t(const CkLocalSys* __r
         }
         return;
     }
-    const double* v = slab + q.off + (long)q.kq * q.ld;
+    const double* v = slab + q.off + (long)(q.kq - 2) * q.ld;
     const double* y = v + q.ld;
     double s1v = 0.0, s2v = 0.0;
     for (int a = tid; a < q.k; a += LP_TPB) {
