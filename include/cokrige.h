@@ -216,8 +216,9 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * ck_factor / ck_predict;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
- * "local_tile_min" (default 256): neighbourhoods with more sites than this are factored by the tiled path of
- * ck_predict_local (batched 64-column steps on the matrix cores) instead of one workgroup per point;
+ * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by
+ * the tiled path of ck_predict_local (batched 64-column steps on the matrix cores) instead of one workgroup per
+ * point (in LDS up to 64 sites, on a global slab above);
  * "local_group" (1..16, default 4) = 64-column blocks per trailing update of that path;
  * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and

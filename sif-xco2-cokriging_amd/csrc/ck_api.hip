@@ -130,7 +130,7 @@ struct ck_handle {
                            // launches cost more than the saved C traffic on small matrices)
     int gemm_variant = CK_GEMM_DEFAULT;   // option "gemm_variant"
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
-    int local_tile_min = 256;    // option "local_tile_min": neighbourhoods larger than this take the tiled path
+    int local_tile_min = 64;     // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
     double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
@@ -1218,7 +1218,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     // Both slab users work in batches that fit a budget (a quarter of the free device memory, at most 32 GiB),
     // so that large radii over many points do not need sum_p k_p^2 doubles at once.
     const int kl = ck_local_lds_limit();
-    const int k_hi = std::max(kl, h->local_tile_min);
+    const int k_hi = h->local_tile_min;   // may lie below the LDS limit: then the LDS kernel only sees k <= k_hi
     std::vector<long long> off(m, 0), need(m, 0);
     std::vector<int64_t> tiled;   // points of the third class
     int64_t kmx = 0, nempty = 0;

@@ -10,14 +10,16 @@
 //                    (forward substitution only: pred = v.y, var = c0 - v.v)
 // Empty neighbourhood -> (NaN, NaN) (:229-233); local Sigma not positive definite -> (NaN, NaN)
 // (:218-222).  Neighbours keep the reference's order: process 0 sites ascending, then process 1.
-// Systems with k <= 124 neighbours live in LDS (k_local_solve); larger ones in a global scratch slab per
-// point with a blocked factorisation (k_local_solve_big).
+// Systems with k <= 64 neighbours live in LDS (k_local_solve); larger ones go through the tiled path (batched
+// 64-column steps on the matrix cores, see below) or, if option "local_tile_min" says so, a global scratch slab
+// per point with a blocked factorisation in one workgroup (k_local_solve_big).
 #include "ck_internal.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 #define LP_TPB 256
-#define LP_KL 124            // (124 + 2) * 124 doubles = 125 KB of LDS
+#define LP_KL 64             // (64 + 2) * 64 doubles = 34 KB of LDS: four workgroups per CU (with 124 and one
+                             // workgroup per CU the kernel was 2x slower than the tiled path from k ~ 40 on)
 
 __device__ __forceinline__ double lp_dist(int metric, double a0, double a1, double a2, double b0, double b1,
                                           double b2) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
                                                          double* __restrict__ slab, double c0var,
                                                          double* __restrict__ pred, double* __restrict__ err,
                                                          long p_base, LpTab T, const double* __restrict__ su,
-                                                         const double* __restrict__ pu, LpSearch R) {
+                                                         const double* __restrict__ pu, LpSearch R, int k_hi) {
     __shared__ double lS[(LP_KL + 2) * LP_KL];
     __shared__ int lidx[LP_KL];
     __shared__ int wsum[LP_TPB / 64];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_solve(const CkMatern* __restri
         }
         return;
     }
-    if (k > LP_KL) return;   // larger systems: k_local_solve_big
+    if (k > LP_KL || k > k_hi) return;   // larger systems: k_local_solve_big / the tiled path
     const double p0 = pc[p], p1 = pc[mpad + p], p2 = pc[2 * mpad + p];
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
     const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;        // chord vectors (table path)
@@ -512,7 +514,7 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
     const LpTab T{tabs, coefs, use_tab};
     const LpSearch R{cb, (long)((L.nend + LP_TPB - 1) / LP_TPB), cmax};
     k_local_solve<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                             counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu, R);
+                                                             counts, slab_off, slab, c0var, pred, err, p_base, T, su, pu, R, k_hi);
     if (slab && k_hi > LP_KL)   // some neighbourhood is larger than the LDS limit
         k_local_solve_big<<<dim3((unsigned)m), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z,
                                                                      L, counts, slab_off, slab, c0var, pred, err,

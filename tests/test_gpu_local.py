@@ -18,9 +18,12 @@ def _predictor(tag):
     return point_prediction.Predictor(mod, mf), g
 
 
+@pytest.mark.parametrize("tile_min", [None, 0, 10 ** 6])   # default classes | everything tiled | LDS + slab kernels
 @pytest.mark.parametrize("tag", ["A", "R"])
-def test_local_prediction_fixture(tag):
+def test_local_prediction_fixture(tag, tile_min):
     P, g = _predictor(tag)
+    if tile_min is not None:
+        P._handle().set_option("local_tile_min", tile_min)
     n_nan = 0
     for i in (0, 1):
         for md in (300, 1000):
