@@ -1185,6 +1185,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     double *d_pc = nullptr, *d_p3 = nullptr, *d_pu = nullptr, *d_out = nullptr, *d_slab = nullptr;
     int* d_cnt = nullptr;
     long long *d_off = nullptr, *d_linfo = nullptr;
+    int* d_k0 = nullptr;
     CkLocalSys* d_sys = nullptr;
     HIPCHK(hipMalloc((void**)&d_pc, 2 * mp * 8));
     HIPCHK(hipMalloc((void**)&d_p3, 3 * mp * 8));
@@ -1304,6 +1305,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     if (!tiled.empty()) {
         HIPCHK(hipMalloc((void**)&d_sys, sysv.size() * sizeof(CkLocalSys)));
         HIPCHK(hipMalloc((void**)&d_linfo, sysv.size() * sizeof(long long)));
+        HIPCHK(hipMalloc((void**)&d_k0, sysv.size() * sizeof(int)));
         HIPCHK(hipMemcpyAsync(d_sys, sysv.data(), sysv.size() * sizeof(CkLocalSys), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemsetAsync(d_linfo, 0, sysv.size() * sizeof(long long), h->stream));
         for (const auto& tb : tbatches) {
@@ -1311,7 +1313,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             const int nb = (int)(tb.second - tb.first);
             ck_launch_local_assemble_t(h->stream, h->d_blk, h->metric, i, cv ? 1 : 0, max_dist, d_p3, mp, h->s0, h->z,
                                        layout_of(h), bsys, nb, d_slab, h->d_tabs, h->d_coefptr, use_tab, h->su, d_pu,
-                                       h->d_chunkb, cmax);
+                                       h->d_chunkb, cmax, d_k0 + tb.first);
             const int kq_max = sysv[tb.first].kq;
             int na = nb;
             const int G = h->local_group;
@@ -1349,6 +1351,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     (void)hipFree(d_off);
     if (d_sys) (void)hipFree(d_sys);
     if (d_linfo) (void)hipFree(d_linfo);
+    if (d_k0) (void)hipFree(d_k0);
     return 0;
 }
 

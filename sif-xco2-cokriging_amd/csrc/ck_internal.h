@@ -166,7 +166,7 @@ void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, 
                                 const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
                                 const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
                                 const double* const* coefs, int use_tab, const double* su, const double* pu,
-                                const double* cb, double cmax);
+                                const double* cb, double cmax, int* k0buf /* n_sys ints of scratch */);
 // Columns are processed in groups of g 64-column blocks [g0, g0 + 64 g): block i of a group first receives the
 // updates of the group's earlier blocks (one pass, K = 64 i), then its diagonal block is factored and inverted and
 // the rows below are solved; the trailing matrix behind the group is updated once with K = 64 g (a g-th of the

@@ -524,31 +524,28 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
 // ---------------------------------------------------------------------------------------
 // tiled path (ck_internal.h: CkLocalSys; the factorisation steps are in ck_la.hip)
 // ---------------------------------------------------------------------------------------
-// neighbour list and the padded local system of every system of a batch, one workgroup per system.
-// The neighbours come out sorted by process (process 0 first), so the lower triangle splits into three
-// regions with ONE Matern block each -- (0,0), (1,0) and (1,1) -- and a region is assembled with its table in
-// LDS, like the joint assembly (ck_cov.hip): chord vectors of LT_BC columns and LT_AC rows staged in LDS, a
-// thread takes one column of four rows at a time (four independent Horner chains), writes run along rows.
-// Entries outside the table (the diagonal, coincident sites, pairs beyond its range) and everything when the
-// tables are off go through the exact evaluator in a second, rolled loop.
-#ifndef LT_ABL
-#define LT_ABL 0
-#endif
+// Neighbour lists and padded local systems of a batch.
+// k_local_search_t (one workgroup per system): the neighbour list, the number k0 of process-0 neighbours, the
+// identity padding, the zeros the 64 x 64 factorisation expects above the diagonal, the c and z rows.
+// k_local_assemble_t (one launch per Matern block): the neighbours come out sorted by process (process 0 first),
+// so the lower triangle splits into three regions with ONE block each -- (0,0), (1,0) and (1,1).  A launch keeps
+// its block's table in LDS, like the joint assembly (ck_cov.hip), and its workgroups walk over the systems
+// (loading 48 KB of table per system cost more than the entries of a 100-site neighbourhood): chord vectors of
+// LT_BC columns and LT_AC rows staged in LDS, a thread takes one column of four rows at a time (four
+// independent Horner chains), writes run along rows.  Entries outside the table (coincident sites, pairs beyond
+// its range) and everything when the tables are off go through the exact evaluator in a second, rolled loop.
 #define LT_BC 1024
 #define LT_AC 256
 #define LT_TPB 512   // 8 waves: with two workgroups per CU (LDS) four waves per SIMD hide the table-read latency
-__global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* __restrict__ blk, int metric, int i_pred,
-                                                                 int cv, double max_dist, const double* __restrict__ pc,
-                                                                 long mpad, const double* __restrict__ sc,
-                                                                 const double* __restrict__ z, CkLayout L,
-                                                                 const CkLocalSys* __restrict__ sys,
-                                                                 double* __restrict__ slab, LpTab T,
-                                                                 const double* __restrict__ su,
-                                                                 const double* __restrict__ pu, LpSearch R) {
-    __shared__ double tab[(CK_TAB_DEG + 1) * CK_TAB_STRIDE];
-    __shared__ double bu[3][LT_BC];
-    __shared__ double au[3][LT_AC];
-    __shared__ int wsum[LT_TPB / 64], wsum0[LT_TPB / 64];
+__global__ __launch_bounds__(LP_TPB) void k_local_search_t(const CkMatern* __restrict__ blk, int metric, int i_pred, int cv,
+                                                            double max_dist, const double* __restrict__ pc, long mpad,
+                                                            const double* __restrict__ sc, const double* __restrict__ z,
+                                                            CkLayout L, const CkLocalSys* __restrict__ sys,
+                                                            double* __restrict__ slab, LpTab T,
+                                                            const double* __restrict__ su,
+                                                            const double* __restrict__ pu, LpSearch R,
+                                                            int* __restrict__ k0out) {
+    __shared__ int wsum[LP_TPB / 64], wsum0[LP_TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const CkLocalSys q = sys[blockIdx.x];
     const long p = q.p;
@@ -561,8 +558,8 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
     double* S = slab + q.off;
     int* idx = reinterpret_cast<int*>(S + (long)CK_LT_ROWS(kq) * ld + 64 * 64);
     int base = 0, k0 = 0;   // k0: neighbours of process 0
-    for (long g0 = 0; g0 < L.nend; g0 += LT_TPB) {   // ordered compaction, as in k_local_solve
-        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2) && lp_chunk_far(R, g0 / LP_TPB + 1, q0, q1, q2)) continue;   // uniform
+    for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {   // ordered compaction, as in k_local_solve
+        if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2)) continue;   // uniform
         const long g = g0 + tid;
         const bool f = g < L.nend && lp_is_neighbour(metric, cv, i_pred, max_dist, L, g, p0, p1, p2, s0, s1, s2);
         const unsigned long long bal = __ballot(f), bal0 = __ballot(f && g < L.n0p);
@@ -575,33 +572,67 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
         int off = base;
         for (int w2 = 0; w2 < wv; ++w2) off += wsum[w2];
         if (f) idx[off + below] = (int)g;
-        for (int w2 = 0; w2 < LT_TPB / 64; ++w2) {
+        for (int w2 = 0; w2 < LP_TPB / 64; ++w2) {
             base += wsum[w2];
             k0 += wsum0[w2];
         }
         __syncthreads();
     }
-#if LT_ABL == 1
-    for (int reg = 0; reg < 0; ++reg) {
-#else
-    for (int reg = 0; reg < 3; ++reg) {
-#endif
+    if (tid == 0) k0out[blockIdx.x] = k0;
+    // zeros up to the end of each row's 4-column diagonal block (the 64 x 64 factorisation loads whole 4 x 4
+    // register blocks); rows [k, kq - 2): identity padding
+    for (int a = tid; a < k; a += LP_TPB)
+        for (int b = a + 1; b <= (a | 3); ++b) S[(long)a * ld + b] = 0.0;
+    for (int a = k; a < kq - 2; ++a)
+        for (int b = tid; b <= (a | 3); b += LP_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
+    // rows kq - 2 (c) and kq - 1 (z): two more rows of the matrix, their own 2 x 2 corner diag(BIG, BIG)
+    for (int a = tid; a < kq; a += LP_TPB) {
+        double cv0 = 0.0, zv = 0.0;
+        if (a < k) {
+            const long ga = idx[a];
+            const int pa = ga >= L.n0p;
+            cv0 = lp_cov(blk, T, i_pred + pa, pa == i_pred, metric, p0, p1, p2, q0, q1, q2, s0[ga], s1[ga], s2[ga], u0[ga],
+                         u1[ga], u2[ga]);   // point_prediction.py:115-125
+            zv = z[ga];
+        }
+        S[(long)(kq - 2) * ld + a] = a == kq - 2 ? CK_LT_BIG : cv0;
+        S[(long)(kq - 1) * ld + a] = a == kq - 1 ? CK_LT_BIG : zv;
+    }
+}
+
+__global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* __restrict__ blk, int metric, int reg,
+                                                                 const double* __restrict__ sc, CkLayout L,
+                                                                 const CkLocalSys* __restrict__ sys, int n_sys,
+                                                                 double* __restrict__ slab, LpTab T,
+                                                                 const double* __restrict__ su,
+                                                                 const int* __restrict__ k0in) {
+    __shared__ double tab[(CK_TAB_DEG + 1) * CK_TAB_STRIDE];
+    __shared__ double bu[3][LT_BC];
+    __shared__ double au[3][LT_AC];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
+    const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;
+    const int nug = reg != 1;
+    const double cdiag = blk[reg].amp + blk[reg].nugget;   // an entry's own site: h = 0 (ck_cov_entry)
+    int tbase = 0, tn = 0;                                  // tn = 0: every entry takes the exact evaluator
+    if (T.use) {
+        tbase = T.tabs[reg].base;
+        tn = T.tabs[reg].n_int;
+        const double* cf = T.coefs[reg];
+        for (int e = tid; e < (CK_TAB_DEG + 1) * tn; e += LT_TPB) {
+            const int kk = e / tn, iv = e - kk * tn;
+            tab[kk * CK_TAB_STRIDE + iv] = cf[kk * CK_TAB_STRIDE + iv];
+        }
+    }
+    for (int sidx = blockIdx.x; sidx < n_sys; sidx += gridDim.x) {
+        const CkLocalSys q = sys[sidx];
+        const int k = q.k, k0 = k0in[sidx];
+        const long ld = q.ld;
+        double* S = slab + q.off;
+        const int* idx = reinterpret_cast<const int*>(S + (long)CK_LT_ROWS(q.kq) * ld + 64 * 64);
         const int alo = reg == 0 ? 0 : k0, ahi = reg == 0 ? k0 : k;
         const int blo = reg == 2 ? k0 : 0, bhi = reg == 2 ? k : k0;
         if (alo >= ahi || blo >= bhi) continue;   // uniform
-        const int nug = reg != 1;
-        const double cdiag = blk[reg].amp + blk[reg].nugget;   // an entry's own site: h = 0 (ck_cov_entry)
-        int tbase = 0, tn = 0;                    // tn = 0: every entry takes the exact evaluator
-        __syncthreads();
-        if (T.use) {
-            tbase = T.tabs[reg].base;
-            tn = T.tabs[reg].n_int;
-            const double* cf = T.coefs[reg];
-            for (int e = tid; e < (CK_TAB_DEG + 1) * tn; e += LT_TPB) {
-                const int kk = e / tn, iv = e - kk * tn;
-                tab[kk * CK_TAB_STRIDE + iv] = cf[kk * CK_TAB_STRIDE + iv];
-            }
-        }
         for (int bc = blo; bc < bhi; bc += LT_BC) {
             const int nbc = min(LT_BC, bhi - bc);
             __syncthreads();
@@ -621,9 +652,11 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
                     au[2][tid] = u2[g];
                 }
                 __syncthreads();
-                for (int r0 = 0; r0 < nac; r0 += 4) {
+                // a wave takes four rows, its lanes the columns: short rows (small neighbourhoods, the top of a
+                // triangle) still fill most of a wave, and a wave's stores are 512 contiguous bytes per row
+                for (int r0 = 4 * wv; r0 < nac; r0 += 4 * (LT_TPB / 64)) {
                     const int nr = min(4, nac - r0), amax = ac + r0 + nr - 1;
-                    for (int bl = tid; bl < nbc && bc + bl <= amax; bl += LT_TPB) {
+                    for (int bl = lane; bl < nbc && bc + bl <= amax; bl += 64) {
                         const int b = bc + bl;
                         const double b0 = bu[0][bl], b1 = bu[1][bl], b2 = bu[2][bl];
                         // four rows of this column at once: chords / interval indices, then all 32 coefficient
@@ -660,22 +693,14 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int a = ac + r0 + r;
-#if LT_ABL == 2
-                            if ((fast >> r & 1u) && pv[r] != pv[r])
-#else
                             if (fast >> r & 1u)
-#endif
                                 S[(long)a * ld + b] = pv[r];
                             else if ((need >> r & 1u) && b == a) {   // one per row: kept out of the slow loop below
                                 S[(long)a * ld + b] = cdiag;
                                 need &= ~(1u << r);
                             }
                         }
-#if LT_ABL == 3
-                        if (need && ld < 0) {
-#else
                         if (need) {
-#endif
                             const long gb = idx[b];
                             const double e0 = s0[gb], e1 = s1[gb], e2 = s2[gb];
 #pragma unroll 1
@@ -691,25 +716,6 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
                 }
             }
         }
-    }
-    // zeros up to the end of each row's 4-column diagonal block (the 64 x 64 factorisation loads whole 4 x 4
-    // register blocks); rows [k, kq - 2): identity padding
-    for (int a = tid; a < k; a += LT_TPB)
-        for (int b = a + 1; b <= (a | 3); ++b) S[(long)a * ld + b] = 0.0;
-    for (int a = k; a < kq - 2; ++a)
-        for (int b = tid; b <= (a | 3); b += LT_TPB) S[(long)a * ld + b] = (b == a) ? 1.0 : 0.0;
-    // rows kq - 2 (c) and kq - 1 (z): two more rows of the matrix, their own 2 x 2 corner diag(BIG, BIG)
-    for (int a = tid; a < kq; a += LT_TPB) {
-        double cv0 = 0.0, zv = 0.0;
-        if (a < k) {
-            const long ga = idx[a];
-            const int pa = ga >= L.n0p;
-            cv0 = lp_cov(blk, T, i_pred + pa, pa == i_pred, metric, p0, p1, p2, q0, q1, q2, s0[ga], s1[ga], s2[ga], u0[ga],
-                         u1[ga], u2[ga]);   // point_prediction.py:115-125
-            zv = z[ga];
-        }
-        S[(long)(kq - 2) * ld + a] = a == kq - 2 ? CK_LT_BIG : cv0;
-        S[(long)(kq - 1) * ld + a] = a == kq - 1 ? CK_LT_BIG : zv;
     }
 }
 
@@ -755,12 +761,16 @@ void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, 
                                 const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
                                 const CkLocalSys* sys, int n_sys, double* slab, const CkTable* tabs,
                                 const double* const* coefs, int use_tab, const double* su, const double* pu,
-                                const double* cb, double cmax) {
+                                const double* cb, double cmax, int* k0buf) {
     if (n_sys <= 0) return;
     const LpTab T{tabs, coefs, use_tab};
     const LpSearch R{cb, (long)((L.nend + LP_TPB - 1) / LP_TPB), cmax};
-    k_local_assemble_t<<<dim3((unsigned)n_sys), dim3(LT_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L,
-                                                                      sys, slab, T, su, pu, R);
+    k_local_search_t<<<dim3((unsigned)n_sys), dim3(LP_TPB), 0, s>>>(blk, metric, i_pred, cv, max_dist, pc, mpad, sc, z, L, sys,
+                                                                    slab, T, su, pu, R, k0buf);
+    const int nreg = L.nend > L.n0p ? 3 : 1;               // a second process?
+    const int grid = n_sys < 512 ? n_sys : 512;            // two workgroups per CU; they walk over the systems
+    for (int reg = 0; reg < nreg; ++reg)
+        k_local_assemble_t<<<dim3((unsigned)grid), dim3(LT_TPB), 0, s>>>(blk, metric, reg, sc, L, sys, n_sys, slab, T, su, k0buf);
 }
 
 void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,
