@@ -1287,11 +1287,23 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
         }
     }
     if (slab_doubles > h->local_slab_doubles) {
-        if (h->local_slab) (void)hipFree(h->local_slab);
-        h->local_slab = nullptr;
-        h->local_slab_doubles = 0;
-        HIPCHK(hipMalloc((void**)&h->local_slab, (size_t)slab_doubles * 8));
-        h->local_slab_doubles = slab_doubles;
+        // Growing is what stalls: hipMalloc of tens of GiB right after a hipFree of a few GiB that were written
+        // took 1-4 s every time (scripts/diag_malloc.py).  So: beyond 1 GiB take the whole budget at once (the
+        // slab then never grows again), and allocate the new slab before releasing the old one.
+        const long long want = slab_doubles * 8 > (1LL << 30) ? std::max(slab_doubles, budget) : slab_doubles;
+        double* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, (size_t)want * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->local_slab) (void)hipFree(h->local_slab);   // not enough room for both
+            h->local_slab = nullptr;
+            h->local_slab_doubles = 0;
+            HIPCHK(hipMalloc((void**)&fresh, (size_t)slab_doubles * 8));
+            h->local_slab_doubles = slab_doubles;
+        } else {
+            if (h->local_slab) (void)hipFree(h->local_slab);
+            h->local_slab_doubles = want;
+        }
+        h->local_slab = fresh;
     }
     if (slab_doubles > 0) d_slab = h->local_slab;
     HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
