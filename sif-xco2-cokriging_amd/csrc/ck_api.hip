@@ -107,6 +107,7 @@ struct ck_handle {
     // empirical variogram state (ck_vario_*)
     std::vector<double> vg_ci, vg_cj;   // host copies of the coordinates (extreme pairs are re-evaluated)
     double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
+    double *vg_ib = nullptr, *vg_jb = nullptr;   // bounding balls of the pair tiles' point blocks (ck_vario.hip)
     int64_t vg_ni = 0, vg_nj = 0;
     int vg_same = 0, vg_grid = 0;
     void* vg_part = nullptr;
@@ -1372,10 +1373,11 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {
     void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
-                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut};
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut, h->vg_ib, h->vg_jb};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
+    h->vg_ib = h->vg_jb = nullptr;
     h->vg_part = nullptr;
     h->vg_psum = nullptr;
     h->vg_pcnt = nullptr;
@@ -1383,17 +1385,43 @@ static void vario_free(ck_handle* h) {
     h->vg_lut = nullptr;
 }
 
-static int vario_upload(ck_handle* h, const double* coords, const double* vals, int64_t n, double** u, double** v) {
+// Upload one field's points.  From 2 048 points on (and unless site_order = 0) they are first laid out along a
+// Hilbert curve: bins sums and counts do not depend on the order of the points (up to rounding of the sums), and
+// compact blocks of points are what lets the kernels skip whole pair tiles (ck_vario.hip, "tile culling").
+// host_coords receives the coordinates in the order the device sees them (the extreme pairs come back as indices).
+static int vario_upload(ck_handle* h, const double* coords, const double* vals, int64_t n, double** u, double** v,
+                        std::vector<double>& host_coords) {
+    host_coords.assign(coords, coords + 2 * n);
+    std::vector<double> hv(vals, vals + n);
+    if (h->site_order && n >= 2048) {
+        double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+        bounding_box(coords, n, lo, hi);
+        std::vector<int64_t> perm;
+        hilbert_order(coords, n, lo, hi, perm);
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t e = perm[(size_t)k];
+            host_coords[2 * k] = coords[2 * e];
+            host_coords[2 * k + 1] = coords[2 * e + 1];
+            hv[(size_t)k] = vals[e];
+        }
+    }
     double* tmp = nullptr;
     HIPCHK(hipMalloc((void**)u, 3 * n * 8));
     HIPCHK(hipMalloc((void**)v, n * 8));
     HIPCHK(hipMalloc((void**)&tmp, 2 * n * 8));
-    HIPCHK(hipMemcpyAsync(tmp, coords, 2 * n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(*v, vals, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(tmp, host_coords.data(), 2 * n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(*v, hv.data(), n * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_vario_prep(h->stream, tmp, n, h->metric, *u, *u + n, *u + 2 * n);
     HIPCHK(hipStreamSynchronize(h->stream));
     (void)hipFree(tmp);
     return 0;
+}
+
+// largest chord |u_i - u_j| of a pair with r <= rlim, with a safety margin (ck_vario.hip: vario_tile_far)
+static double vario_cmax(int metric, double rlim) {
+    const double c = metric == CK_METRIC_HAVERSINE ? 2.0 * sqrt(rlim) : sqrt(rlim);
+    const double m = c * (1.0 + 1e-9) + 1e-12;
+    return m == m ? m : INFINITY;
 }
 
 extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double* resid_i, int64_t n_i,
@@ -1404,8 +1432,7 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
     vario_free(h);
     h->vg_same = same ? 1 : 0;
     h->vg_ni = n_i;
-    h->vg_ci.assign(coords_i, coords_i + 2 * n_i);
-    if (vario_upload(h, coords_i, resid_i, n_i, &h->vg_iu, &h->vg_iv)) return -1;
+    if (vario_upload(h, coords_i, resid_i, n_i, &h->vg_iu, &h->vg_iv, h->vg_ci)) return -1;
     if (same) {
         h->vg_nj = n_i;
         h->vg_cj = h->vg_ci;
@@ -1413,9 +1440,13 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
         h->vg_jv = h->vg_iv;
     } else {
         h->vg_nj = n_j;
-        h->vg_cj.assign(coords_j, coords_j + 2 * n_j);
-        if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv)) return -1;
+        if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv, h->vg_cj)) return -1;
     }
+    HIPCHK(hipMalloc((void**)&h->vg_ib, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 0) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1) * 8)));
+    ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 0, h->vg_ib);
+    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1, h->vg_jb);
+    HIPCHK(hipGetLastError());
     h->vg_grid = ck_vario_grid(h->vg_ni, h->vg_nj);
     HIPCHK(hipMalloc(&h->vg_part, h->vg_grid * sizeof(CkVarioExt)));
     HIPCHK(hipMalloc((void**)&h->vg_psum, (size_t)h->vg_grid * CK_VG_MAXBINS * 8));
@@ -1439,7 +1470,7 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     if (!h->vg_iu) return fail("ck_vario_begin has not been called");
     const double rcap = vario_r_of_dist(h->metric, max_dist);
     ck_launch_vario_extent(h->stream, h->vg_grid, h->metric, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj,
-                           rcap, h->vg_part, h->rank, h->world);
+                           rcap, h->vg_part, h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(h->metric, rcap));
     HIPCHK(hipGetLastError());
     std::vector<CkVarioExt> part(h->vg_grid);
     HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost,
@@ -1509,7 +1540,8 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     ck_launch_vario_bin(h->stream, h->vg_grid, h->metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv,
                         h->vg_ni, h->vg_ju, h->vg_jv, h->vg_nj, rcap, nb, d_thr, h->vg_lut, 1.0 / cell, h->vg_psum,
-                        h->vg_pcnt, d_sums, d_cnt, h->rank, h->world);
+                        h->vg_pcnt, d_sums, d_cnt, h->rank, h->world, h->vg_ib, h->vg_jb,
+                        vario_cmax(h->metric, fmin(rcap, thr[nb])));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     long long cnt[CK_VG_MAXBINS];

@@ -115,11 +115,17 @@ void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int me
 int ck_vario_grid(int64_t ni, int64_t nj);
 // iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]
 void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
-                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world);
+                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world,
+                            const double* ib, const double* jb, double cmax);
+// tile culling (ck_vario.hip): bounding balls of the 256-point "i" blocks / 1024-point "j" chunks, 4 x nblk doubles;
+// cmax = largest chord |u_i - u_j| of a retained pair (with margin); ib == nullptr switches the culling off
+int64_t ck_vario_nblocks(int64_t n, int j_side);
+void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int j_side, double* out);
 void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
                          const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
                          int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
-                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world);
+                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world,
+                         const double* ib, const double* jb, double cmax);
 
 // ---- local-neighbourhood cokriging (ck_local.hip) -------------------------------------------
 // pc: 3 x mpad prediction-site coordinates, sc: 3 x npad site coordinates (exact-formula form)

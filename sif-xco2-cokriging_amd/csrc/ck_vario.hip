@@ -64,6 +64,64 @@ struct TileMap {
     long nI, nJ;
 };
 
+// ---- tile culling -------------------------------------------------------------------------------------
+// The host lays the points out along a Hilbert curve (ck_api.hip: vario_upload), so the 256 "i" points of a
+// tile and the 1024 "j" points of its chunk are two compact patches.  Per block of points: the mean c of its
+// vectors u and rad = max |u - c|.  Every pair of a tile has |u_i - u_j| >= |c_I - c_J| - rad_I - rad_J; if that
+// already exceeds the largest retained chord the whole tile is skipped -- with max_dist = 1 500 km on CONUS
+// three tiles in four.  (A pair that is not retained costs the binning pass exactly what a retained one does.)
+// bounds: 4 x nblk doubles (c.x, c.y, c.z, rad).
+__global__ __launch_bounds__(VG_TPB) void k_vario_bounds(const double* __restrict__ u0, const double* __restrict__ u1,
+                                                          const double* __restrict__ u2, long n, int blk, long nblk,
+                                                          double* __restrict__ out) {
+    __shared__ double red[3][VG_TPB];
+    const int tid = threadIdx.x;
+    const long lo = (long)blockIdx.x * blk, hi = (lo + blk < n) ? lo + blk : n;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (long g = lo + tid; g < hi; g += VG_TPB) {
+        sx += u0[g];
+        sy += u1[g];
+        sz += u2[g];
+    }
+    red[0][tid] = sx;
+    red[1][tid] = sy;
+    red[2][tid] = sz;
+    __syncthreads();
+    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s)
+            for (int c = 0; c < 3; ++c) red[c][tid] += red[c][tid + s];
+        __syncthreads();
+    }
+    const double inv = 1.0 / (double)(hi - lo);
+    const double cx = red[0][0] * inv, cy = red[1][0] * inv, cz = red[2][0] * inv;
+    __syncthreads();
+    double rm = 0.0;
+    for (long g = lo + tid; g < hi; g += VG_TPB) {
+        const double dx = u0[g] - cx, dy = u1[g] - cy, dz = u2[g] - cz;
+        rm = fmax(rm, sqrt(dx * dx + dy * dy + dz * dz));
+    }
+    red[0][tid] = rm;
+    __syncthreads();
+    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) red[0][tid] = fmax(red[0][tid], red[0][tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[blockIdx.x] = cx;
+        out[nblk + blockIdx.x] = cy;
+        out[2 * nblk + blockIdx.x] = cz;
+        out[3 * nblk + blockIdx.x] = red[0][0] * (1.0 + 1e-12);
+    }
+}
+
+// cmax: largest chord |u_i - u_j| a retained pair can have, with its safety margin (host); bounds may be null
+__device__ __forceinline__ bool vario_tile_far(const double* __restrict__ ib, long nI, long bi,
+                                               const double* __restrict__ jb, long nJ, long bj, double cmax) {
+    if (!ib) return false;
+    const double dx = ib[bi] - jb[bj], dy = ib[nI + bi] - jb[nJ + bj], dz = ib[2 * nI + bi] - jb[2 * nJ + bj];
+    return sqrt(dx * dx + dy * dy + dz * dz) - ib[3 * nI + bi] - jb[3 * nJ + bj] > cmax;
+}
+
 // ---- pass 1: extreme pairs ------------------------------------------------------------------------
 __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, const double* __restrict__ iu0,
                                                           const double* __restrict__ iu1,
@@ -71,7 +129,9 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
                                                           const double* __restrict__ ju0,
                                                           const double* __restrict__ ju1,
                                                           const double* __restrict__ ju2, long nj, double rcap,
-                                                          VarioPartialExt* __restrict__ part, int rank, int world) {
+                                                          VarioPartialExt* __restrict__ part, int rank, int world,
+                                                          const double* __restrict__ ib, const double* __restrict__ jb,
+                                                          double cmax) {
     __shared__ double red_r[VG_TPB];
     __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
     const int tid = threadIdx.x;
@@ -83,6 +143,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
+        if (vario_tile_far(ib, nI, bi, jb, nJ, bj, cmax)) continue;   // no pair of this tile within max_dist
         const long i = i0 + tid;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
@@ -164,7 +225,9 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
                                                        int nb, const double* __restrict__ thr,
                                                        const unsigned char* __restrict__ lut, double inv_cell,
                                                        double* __restrict__ part_sum,
-                                                       unsigned long long* __restrict__ part_cnt, int rank, int world) {
+                                                       unsigned long long* __restrict__ part_cnt, int rank, int world,
+                                                       const double* __restrict__ ib, const double* __restrict__ jb,
+                                                       double cmax) {
     __shared__ double hsum[VG_MAXBINS + 1][VG_TPB];        // + 1: the trash row of pairs that are not retained
     __shared__ unsigned int hcnt[VG_MAXBINS + 1][VG_TPB];
     __shared__ double sthr[VG_MAXBINS + 2];
@@ -222,6 +285,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
+        if (vario_tile_far(ib, nI, bi, jb, nJ, bj, cmax)) continue;   // no retained pair in this tile
         const long i = i0 + tid;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
@@ -290,17 +354,28 @@ int ck_vario_grid(int64_t ni, int64_t nj) {
 }
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
-                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world) {
+                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world,
+                            const double* ib, const double* jb, double cmax) {
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj,
-                                                       ju + 2 * nj, nj, rcap, (VarioPartialExt*)part, rank, world);
+                                                       ju + 2 * nj, nj, rcap, (VarioPartialExt*)part, rank, world, ib, jb,
+                                                       cmax);
+}
+
+// bounding balls of the "i" blocks (VG_TPB points) or the "j" chunks (VG_JCHUNK points): 4 x nblk doubles
+int64_t ck_vario_nblocks(int64_t n, int j_side) { return j_side ? (n + VG_JCHUNK - 1) / VG_JCHUNK : (n + VG_TPB - 1) / VG_TPB; }
+void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int j_side, double* out) {
+    const int64_t nblk = ck_vario_nblocks(n, j_side);
+    if (nblk <= 0) return;
+    k_vario_bounds<<<dim3((unsigned)nblk), dim3(VG_TPB), 0, s>>>(u, u + n, u + 2 * n, n, j_side ? VG_JCHUNK : VG_TPB, nblk, out);
 }
 
 void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
                          const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
                          int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
-                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world) {
+                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world,
+                         const double* ib, const double* jb, double cmax) {
     k_vario_bin<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, covariogram, iu, iu + ni, iu + 2 * ni, iv, ni, ju,
                                                     ju + nj, ju + 2 * nj, jv, nj, rcap, nb, thr, lut, inv_cell,
-                                                    part_sum, part_cnt, rank, world);
+                                                    part_sum, part_cnt, rank, world, ib, jb, cmax);
     k_vario_final<<<dim3(1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, sums, counts);
 }
