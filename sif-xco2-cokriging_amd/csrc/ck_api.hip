@@ -133,6 +133,7 @@ struct ck_handle {
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     int local_tile_min = 64;     // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
+    int64_t loo_g0 = -1;              // >= 0 during ck_loocv: right-hand-side row 1 + p is the unit vector of site loo_g0 + p
     double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
     long long local_slab_doubles = 0; // costs up to seconds, erratically); grows when a call needs more
@@ -765,15 +766,26 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
 }
 
 // forward substitution of the right-hand-side rows with the diagonal block of panel K
+// Right-hand-side rows that can be nonzero in the columns of panels <= K (a multiple of CK_AUX_ALIGN).  Prediction: all.
+// Leave-one-out (ck_loocv): row 0 is dense, row 1 + p starts at column loo_g0 + p -- the rows are sorted by their
+// first nonzero column, so the sweep works on a growing prefix (process 0: 58 % of the full sweep's flops,
+// process 1: 8 %).
+static int64_t aux_rows(const ck_handle* h, int K) {
+    if (h->loo_g0 < 0) return h->mpad;
+    const int64_t live = (int64_t)(K + 1) * CK_NB - h->loo_g0 + 1;   // rows 0 .. live - 1
+    return std::min(h->mpad, roundup(std::max<int64_t>(live, 1), CK_AUX_ALIGN));
+}
+
 static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     const double* tail = P + (h->Npad - (int64_t)K * CK_NB) * CK_NB;
+    const int64_t rows = aux_rows(h, K);
     for (int q = 0; q < CK_NB / CK_IB; ++q) {
-        ck_launch_trsm64(st, X + q * CK_IB, CK_NB, h->mpad, tail + (int64_t)q * CK_IB * CK_IB);
+        ck_launch_trsm64(st, X + q * CK_IB, CK_NB, rows, tail + (int64_t)q * CK_IB * CK_IB);
         const int64_t r1 = (int64_t)(q + 1) * CK_IB;
         const int64_t ncols = CK_NB - r1;
         if (ncols > 0)
-            ck_launch_gemm_nt(st, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB, h->mpad,
+            ck_launch_gemm_nt(st, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB, rows,
                               ncols, CK_IB, 0, 0, 1, 0, 0, 0, h->gemm_variant);
     }
 }
@@ -783,12 +795,13 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     const int nJ = Jhi - Jlo + 1;
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
+    const int64_t rows = aux_rows(h, K);
     if (timed) gemm_timed_begin(h, st);
     if (h->gemm_variant == 7 || h->gemm_variant == 8)
-        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, h->gemm_variant);
+        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, h->gemm_variant, rows);
     else
         ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
-                          P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, h->mpad, CK_NB, CK_NB, 0, 0, nJ,
+                          P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, rows, CK_NB, CK_NB, 0, 0, nJ,
                           h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB, h->gemm_variant);
     if (timed) gemm_timed_end(h, st);
 }
@@ -929,14 +942,16 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, h->gemm_variant);
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, h->gemm_variant,
+                                        aux_rows(h, K0 + g - 1));
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->gemm_variant);
+                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->gemm_variant,
+                                    aux_rows(h, K0 + Gc - 1));
                 gemm_timed_end(h);
             }
         }
@@ -971,10 +986,11 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     return 0;
 }
 
+// pcoords == nullptr: storage only (ck_loocv fills the right-hand-side rows itself)
 static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m, bool may_sort) {
     if (ensure_layout(h)) return -1;
     if (i < 0 || i >= h->n_procs) return fail("process index out of range");
-    if (m < 0 || (m > 0 && !pcoords)) return fail("bad pcoords");
+    if (m < 0) return fail("bad pcoords");
     const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
     const int64_t need = mpad * h->Npad;
     if (need > h->aux_cap) {
@@ -1003,6 +1019,10 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
     // large sets of prediction points are laid out along the Hilbert curve like the data sites
     // (site_order above); ck_aux_finish hands the results back in the caller's order
     std::vector<double> sorted;
+    if (!pcoords) {
+        h->p_sorted = false;
+        return 0;
+    }
     h->p_sorted = may_sort && h->site_order && m >= 256;
     if (h->p_sorted) {
         double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
@@ -1044,6 +1064,7 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
 
 extern "C" int ck_aux_begin(ck_handle* h, int i, const double* pcoords, int64_t m) {
     CHKH(h);
+    if (m > 0 && !pcoords) return fail("bad pcoords");
     return aux_begin_impl(h, i, pcoords, m, true);
 }
 
@@ -1145,19 +1166,28 @@ extern "C" int ck_loocv(ck_handle* h, int i, double* pred, double* pred_err) {
     if (i < 0 || i >= h->n_procs) return fail("process index out of range");
     const int64_t m = h->n[i];
     if (m <= 0) return 0;
-    // reuse the aux machinery: allocate as for m prediction points (coordinates unused)
-    std::vector<double> dummy(2 * m, 0.0);
-    if (aux_begin_impl(h, i, dummy.data(), m, false)) return -1;
+    // reuse the aux machinery: storage as for m prediction points; m + 1 rows:
+    // row 0 = z, row 1 + q = unit vector of datum q
+    if (aux_begin_impl(h, i, nullptr, m, false)) return -1;
     HIPCHK(hipMemsetAsync(h->aux, 0, (size_t)h->mpad * h->Npad * 8, h->stream));
-    ck_launch_loo_rows(h->stream, h->aux, h->mpad, m, i == 0 ? 0 : h->n0p, h->z, h->Npad);
-    HIPCHK(hipGetLastError());
-    if (solve_sweep(h)) return -1;
-    ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, m, m, -1.0, h->d_pred, h->d_err);
+    h->loo_g0 = i == 0 ? 0 : h->n0p;
+    ck_launch_loo_rows(h->stream, h->aux, h->mpad, m, h->loo_g0, h->z, h->Npad);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    const int rc = solve_sweep(h);
+    h->loo_g0 = -1;
+    if (rc) return -1;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    ck_launch_reduce_pred(h->stream, h->aux, h->mpad, h->nK, m + 1, 0, -1.0, h->d_pred, h->d_err);
     HIPCHK(hipGetLastError());
     std::vector<double> s1(m), s2(m);
-    HIPCHK(hipMemcpyAsync(s1.data(), h->d_pred, m * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(s2.data(), h->d_err, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(s1.data(), h->d_pred + 1, m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(s2.data(), h->d_err + 1, m * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->t_ms[3] = ms;
+    }
     const double* zi = h->h_values[i].data();
     for (int64_t q = 0; q < m; ++q) {   // q: internal position; results go to the caller's index
         const int64_t x = h->perm[i][(size_t)q];

@@ -83,7 +83,7 @@ void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
                           int Jstep, int nJ, int64_t Npad, int variant);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int variant);
+                         int nJ, int variant, int64_t mrows);
 void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
                            int nJ, int64_t Npad, int variant);
 // In-place Cholesky of the 64 x 64 diagonal block at A (ld); info_dev gets global_index0 + j + 1 of

@@ -756,11 +756,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(double* __restrict__ aux, long mpad,
-                                                        double* const* __restrict__ sigptr, int K0, int np, int J0) {
+                                                        double* const* __restrict__ sigptr, int K0, int np, int J0,
+                                                        long mrows) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y;
     const int tiles_n = CK_NB / 128;
-    const int nblk = (int)(mpad / 128) * tiles_n;
+    const int nblk = (int)(mrows / 128) * tiles_n;   // the first mrows of the mpad rows (the others are known zeros)
     const int t = xcd_remap(blockIdx.x, nblk);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
@@ -789,11 +790,11 @@ __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) vo
 // aux block columns J = J0 + blockIdx.y -= sum over p of aux[K0 + p] L[J, K0 + p]^T
 template <int WAVES, int TN>
 __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_aux_group(
-    double* __restrict__ aux, long mpad, double* const* __restrict__ sigptr, int K0, int np, int J0) {
+    double* __restrict__ aux, long mpad, double* const* __restrict__ sigptr, int K0, int np, int J0, long mrows) {
     __shared__ __attribute__((aligned(16))) char lds[2 * (128 + TN) * 128];
     const int J = J0 + (int)blockIdx.y;
     const int tiles_n = CK_NB / TN;
-    const int nblk = (int)(mpad / 128) * tiles_n;
+    const int nblk = (int)(mrows / 128) * tiles_n;
     const int t = xcd_remap(blockIdx.x, nblk);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * TN;
@@ -827,27 +828,25 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
         k_syrk_group<8, 128><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
 }
 
+// mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
+// sweep knows that the others are still zero in these columns
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int variant) {
-    if (nJ <= 0 || np <= 0 || mpad <= 0) return;
+                         int nJ, int variant, int64_t mrows) {
+    if (nJ <= 0 || np <= 0 || mrows <= 0) return;
     if (variant == 6) {
-        const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 64)), (unsigned)nJ);
-        k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 64)), (unsigned)nJ);
+        k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
         return;
     }
-    if (variant == 7 || variant == 8) {
-        const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-        if (variant == 7)
-            k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
-        else
-            k_aux_group_d<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
-        return;
-    }
-    const dim3 grid((unsigned)((mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (variant == 4)
-        k_aux_group<4, 128><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+    const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 128)), (unsigned)nJ);
+    if (variant == 7)
+        k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
+    else if (variant == 8)
+        k_aux_group_d<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
+    else if (variant == 4)
+        k_aux_group<4, 128><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
     else
-        k_aux_group<8, 128><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0);
+        k_aux_group<8, 128><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
 }
 
 // plain (optionally batched over blockIdx.y) form
@@ -1336,16 +1335,17 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const double* __restrict__ 
     }
 }
 
-// right-hand sides of the leave-one-out sweep: row p = unit vector of datum p of the withheld
-// process (internal index g0 + p), row m = the data values z
+// right-hand sides of the leave-one-out sweep: row 0 = the data values z, row 1 + p = unit vector of datum p of
+// the withheld process (internal index g0 + p).  Row 1 + p is zero in every column before g0 + p, so the sweep
+// only needs the first rows up to the current panel (ck_api.hip: aux_rows).
 __global__ void k_loo_rows(double* __restrict__ aux, long mpad, long m, long g0, const double* __restrict__ z,
                            long npad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) {
+    if (i < m) {   // row 1 + i: unit vector of datum i (site g0 + i)
         const long g = g0 + i;
-        aux[(g / CK_NB) * mpad * CK_NB + i * CK_NB + (g % CK_NB)] = 1.0;
+        aux[(g / CK_NB) * mpad * CK_NB + (i + 1) * CK_NB + (g % CK_NB)] = 1.0;
     }
-    if (i < npad) aux[(i / CK_NB) * mpad * CK_NB + m * CK_NB + (i % CK_NB)] = z[i];
+    if (i < npad) aux[(i / CK_NB) * mpad * CK_NB + (i % CK_NB)] = z[i];   // row 0: the data values
 }
 
 // out[r] = sum_{c <= r} L[r][c] v[c] over the packed panels (simulation draw z = L eps, src/sim.py:52-54)
