@@ -1227,19 +1227,53 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ S, long ld, in
     }
 }
 
-// diagonal block of block column jb = g0 + 64 i: its in-group update, then the factorisation and the inverse
+// in-group update of the diagonal block itself:  D -= A A^T,  A = S[jb .. jb + 63, g0 .. jb); both operands are the
+// same rows, so ONE 64 x 66 LDS array M serves as A and as B
+__device__ __forceinline__ void lt_diag_update(double* __restrict__ S, long ld, int g0, int i, double* M) {
+    constexpr int PITCH = 66;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int jb = g0 + 64 * i;
+    const double* Ar = S + (long)jb * ld + g0;
+    double* C = S + (long)jb * ld + jb;
+    const int sr = tid >> 6, sc = tid & 63;
+    d4_t acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int ks = 0; ks < i; ++ks) {
+        if (ks) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) M[(sr + 4 * u) * PITCH + sc] = Ar[(long)(sr + 4 * u) * ld + 64 * ks + sc];
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const double av = M[(16 * w + li) * PITCH + 4 * s2 + g];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, M[(16 * jt + li) * PITCH + 4 * s2 + g], acc[jt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] -= acc[jt][r];
+}
+
+// diagonal block of block column jb = g0 + 64 i: its in-group update, then the factorisation and the inverse.
+// One LDS array for everything (36 KB with the small vectors: four workgroups per CU instead of two): inside
+// potrf64_body the transposed factor lives in the block-upper part (Lt[c][i], c <= i) and the inverse in the
+// block-lower part (Wi[r][c], c <= r); the 16 x 16 diagonal blocks of Lt are dead once step A of the inverse has
+// read them, which is when the diagonal blocks of Wi are written (same wave, program order).
 __global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
                                                      int i, long long* info) {
-    __shared__ __attribute__((aligned(16))) double Lt[64][66];
-    __shared__ __attribute__((aligned(16))) double Wi[64][66];
+    __shared__ __attribute__((aligned(16))) double M[64][66];
     const CkLocalSys q = sys[blockIdx.x];
     double* S = slab + q.off;
     const int jb = g0 + 64 * i;
     if (i > 0) {
-        lt_rows_body<false>(S, q.ld, g0, i, jb, nullptr, &Lt[0][0], &Wi[0][0]);
+        lt_diag_update(S, q.ld, g0, i, &M[0][0]);
         __syncthreads();   // the block is re-read from memory by other threads of this workgroup
     }
-    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, Lt, Wi);
+    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, M, M);
 }
 
 // rows below the diagonal block: in-group update and row solve
