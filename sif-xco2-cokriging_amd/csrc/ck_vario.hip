@@ -27,6 +27,7 @@
 #define VG_MAXBINS 36
 #define VG_LUT 8192
 #define VG_G 8           // pairs per lane processed together (k_vario_bin); 16 measured slower
+#define VG_W 8           // bins a tile's pairs may span for the compare-only binning (k_vario_bin)
 
 struct VarioPartialExt {
     double rmin, rmax;
@@ -278,6 +279,31 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
             atomicAdd(&hcnt[bb][tid], keep[u] ? 1u : 0u);                                                       \
         }                                                                                                       \
     }
+    // The same group for a tile whose pairs can only fall into the VG_W bins wb .. wb + VG_W - 1 (decided per tile
+    // from the bounding balls): the bin is wb + the number of the window's inner edges below r -- compares against
+    // seven wave-uniform thresholds instead of three dependent LDS lookups.
+#define VG_GROUP8W(FULL)                                                                                        \
+    {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < VG_G; ++u) {                                                         \
+            const long kk = (FULL) ? kg + u : (kg + u < jend ? kg + u : jend - 1);                              \
+            const double r = pair_r(metric, ax, ay, az, ju0[j0 + kk], ju1[j0 + kk], ju2[j0 + kk]);              \
+            const double bvu = jv[j0 + kk];                                                                     \
+            const bool keep = live && ((FULL) || kg + u < jend) && kg + u >= kbeg && r <= rcap && r <= rtop;    \
+            int b = wb;                                                                                         \
+            _Pragma("unroll") for (int w = 0; w < VG_W - 1; ++w) b += (r > wt[w]) ? 1 : 0;                         \
+            double cl;                                                                                          \
+            if (covariogram) {                                                                                  \
+                cl = av * bvu;                                                                                  \
+            } else {                                                                                            \
+                const double df = av - bvu;                                                                     \
+                cl = 0.5 * (df * df);                                                                           \
+            }                                                                                                   \
+            const int bb = keep ? b : nb;                                                                       \
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&hsum[bb][tid],      \
+                                                keep ? cl : 0.0);                                               \
+            atomicAdd(&hcnt[bb][tid], keep ? 1u : 0u);                                                          \
+        }                                                                                                       \
+    }
     const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     // per-lane 64-bit count spill: hcnt is 32-bit, a lane sees at most nJ * VG_JCHUNK pairs per I block
     // tile list sharded over processes (ck_set_partition): this one takes the tiles t = rank (mod world)
@@ -285,7 +311,32 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
-        if (vario_tile_far(ib, nI, bi, jb, nJ, bj, cmax)) continue;   // no retained pair in this tile
+        // bounding balls of the two point blocks: chords of this tile's pairs lie in [dlo, dhi]
+        double dlo = 0.0, dhi = 1e300;
+        if (ib) {
+            const double dx = ib[bi] - jb[bj], dy = ib[nI + bi] - jb[nJ + bj], dz = ib[2 * nI + bi] - jb[2 * nJ + bj];
+            const double dc = sqrt(dx * dx + dy * dy + dz * dz), rr = ib[3 * nI + bi] + jb[3 * nJ + bj];
+            dlo = dc - rr;
+            dhi = dc + rr;
+        }
+        if (dlo > cmax) continue;   // no retained pair in this tile
+        // bin window of the tile (margins far above the rounding of either side): every pair has
+        // wb <= bin <= wbhi; the fast group needs the window to fit VG_W bins
+        int wb = 0, wbhi = nb - 1;
+        if (ib) {
+            const double sc = metric == CK_METRIC_HAVERSINE ? 0.25 : 1.0;
+            const double lo1 = fmax(dlo, 0.0) * (1.0 - 1e-9), hi1 = dhi * (1.0 + 1e-9) + 1e-12;
+            const double rlo = sc * lo1 * lo1 * (1.0 - 1e-12), rhi = sc * hi1 * hi1 * (1.0 + 1e-12);
+            wbhi = 0;
+            for (int e = 1; e < nb; ++e) {
+                wb += (rlo > sthr[e]) ? 1 : 0;
+                wbhi += (rhi > sthr[e]) ? 1 : 0;
+            }
+        }
+        const bool narrow = ib && wbhi - wb < VG_W;
+        double wt[VG_W - 1];   // the window's inner edges thr[wb + 1 ..], +inf beyond the last bin
+#pragma unroll
+        for (int w = 0; w < VG_W - 1; ++w) wt[w] = (wb + 1 + w < nb) ? sthr[wb + 1 + w] : 1e300;
         const long i = i0 + tid;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
@@ -306,11 +357,17 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
         // ds_add_u32): sequential per lane in program order, hence deterministic; pairs that are not
         // retained add 0 to a trash row (index nb).
         long kg = k0;
-        for (; kg + VG_G <= jend; kg += VG_G)      // full groups: consecutive scalar loads merge into s_load_dwordx16
-            VG_GROUP8(true);
-        for (; kg < jend; kg += VG_G) VG_GROUP8(false);   // tail: indices clamped, pairs beyond jend masked
+        if (narrow) {
+            for (; kg + VG_G <= jend; kg += VG_G) VG_GROUP8W(true);
+            for (; kg < jend; kg += VG_G) VG_GROUP8W(false);
+        } else {
+            for (; kg + VG_G <= jend; kg += VG_G)      // full groups: consecutive scalar loads merge into s_load_dwordx16
+                VG_GROUP8(true);
+            for (; kg < jend; kg += VG_G) VG_GROUP8(false);   // tail: indices clamped, pairs beyond jend masked
+        }
     }
 #undef VG_GROUP8
+#undef VG_GROUP8W
     __syncthreads();
     // reduce the 256 private histograms: thread b sums bin b in lane order (deterministic)
     if (tid < nb) {
