@@ -214,6 +214,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
  * ck_factor / ck_predict;
+ * "panel_fused" (0..3, default 2; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
+ * 64-column sub-blocks are processed left-looking with the update and the row solve fused into one launch;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
  * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by

@@ -91,6 +91,10 @@ void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const doubl
 void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
                        double* Linv);
 // X L^T = A in place for `nrows` rows of A (ld), 64 columns; L (64 x 64 lower, ldl).  nrows % 64 == 0.
+// fused panel step (ck_la.hip, option "panel_fused")
+void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv);
+void ck_launch_panel_rows(hipStream_t s, double* X, int64_t row_first, int64_t nrows, const double* P, int j,
+                          const double* Linv);
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* Linv);
 // pred[p] = sum_c X[p][c] y[c];  err[p] = nan_to_num(sqrt(c0 - sum_c X[p][c]^2)); X rows live in
 // n_panels panels of width CK_NB at aux + K * mpad * CK_NB; y is row `zrow`.

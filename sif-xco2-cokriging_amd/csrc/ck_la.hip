@@ -1147,22 +1147,21 @@ void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const
 // in one pass over the chunk.  K slabs of 64 columns are staged through LDS with the next slab already in
 // flight in registers; the chunk of C is loaded straight into the MFMA result layout before the K loop.
 // As, Bs: 64 x 66 doubles of LDS each.
+// C: the chunk (64 x 64, leading dimension ld); Ar: the chunk's rows, first of the 64 i earlier columns (same ld);
+// Br: the 64 rows of the block's own diagonal range, same columns (leading dimension ldb).
 template <bool SOLVE>
-__device__ __forceinline__ void lt_rows_body(double* __restrict__ S, long ld, int g0, int i, int row0,
+__device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const double* __restrict__ Ar, long ld,
+                                             const double* __restrict__ Br, long ldb, int i,
                                              const double* __restrict__ Linv, double* As, double* Bs) {
     constexpr int PITCH = 66;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int jb = g0 + 64 * i;
-    const double* Ar = S + (long)row0 * ld + g0;
-    const double* Br = S + (long)jb * ld + g0;
-    double* C = S + (long)row0 * ld + jb;
     const int sr = tid >> 6, sc = tid & 63;   // staging: element (sr + 4 u, sc), u < 16
     double ra[16], rb[16];
     if (i > 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
-            rb[u] = Br[(long)(sr + 4 * u) * ld + sc];
+            rb[u] = Br[(long)(sr + 4 * u) * ldb + sc];
         }
     }
     d4_t cn[4];
@@ -1181,7 +1180,7 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ S, long ld, in
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
-                rb[u] = Br[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
+                rb[u] = Br[(long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc];
             }
         } else if (SOLVE) {
 #pragma unroll
@@ -1286,7 +1285,49 @@ __global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict
     const int nchunk = (q.kq - jb - 64) / 64;   // rows jb + 64 .. kq - 1
     if ((int)blockIdx.x >= nchunk) return;
     double* S = slab + q.off;
-    lt_rows_body<true>(S, q.ld, g0, i, jb + 64 + 64 * (int)blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, As, Bs);
+    const long row0 = jb + 64 + 64 * (long)blockIdx.x;
+    lt_rows_body<true>(S + row0 * q.ld + jb, S + row0 * q.ld + g0, q.ld, S + (long)jb * q.ld + g0, q.ld, i,
+                       S + (long)CK_LT_ROWS(q.kq) * q.ld, As, Bs);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same two kernels inside a 512-column panel of the joint factorisation (option "panel_fused"): sub-block j
+// first receives the updates of the panel's earlier sub-blocks (left-looking, K = 64 j), then is factored /
+// solved -- two launches per sub-block instead of three (potrf64, trsm64m, a K = 64 update of the rest of the
+// panel), and every 64-column strip of the panel is read and written once instead of once per earlier sub-block.
+// P: packed panel (rows x CK_NB, row 0 = the panel's own first row).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_panel_diag(double* __restrict__ P, int j, long g0, long long* info,
+                                                     double* __restrict__ Linv) {
+    __shared__ __attribute__((aligned(16))) double M[64][66];
+    const int jb = 64 * j;
+    if (j > 0) {
+        lt_diag_update(P, CK_NB, 0, j, &M[0][0]);
+        __syncthreads();
+    }
+    potrf64_body(P + (long)jb * CK_NB + jb, CK_NB, g0 + jb, info, Linv, M, M);
+}
+
+// rows below the diagonal block of sub-block j: C = X[rows, 64 j ..] (X == P for the factorisation; the
+// right-hand-side rows of the solve sweep otherwise), updates from X[rows, 0 .. 64 j) and P[64 j .. 64 j + 63, 0 .. 64 j)
+__global__ __launch_bounds__(256, 2) void k_panel_rows(double* X, long row_first, const double* P,
+                                                        int j, const double* __restrict__ Linv) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    const int jb = 64 * j;
+    const long row0 = row_first + 64 * (long)blockIdx.x;
+    lt_rows_body<true>(X + row0 * CK_NB + jb, X + row0 * CK_NB, CK_NB, P + (long)jb * CK_NB, CK_NB, j, Linv, As, Bs);
+}
+
+void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv) {
+    k_panel_diag<<<dim3(1), dim3(256), 0, s>>>(P, j, g0, info, Linv);
+}
+
+// nrows (a multiple of 64) rows of X starting at row_first
+void ck_launch_panel_rows(hipStream_t s, double* X, int64_t row_first, int64_t nrows, const double* P, int j,
+                          const double* Linv) {
+    if (nrows <= 0) return;
+    k_panel_rows<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(X, row_first, P, j, Linv);
 }
 
 // trailing update behind a group of columns [g0, g0 + K):  C -= A A^T on 128 x 128 tiles, rows and columns

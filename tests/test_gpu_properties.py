@@ -69,6 +69,29 @@ def test_panel_groups_and_tile_variants(group, variant):
         h.close()
 
 
+@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+def test_panel_fused_variants(fused):
+    """option panel_fused: the 64-column sub-blocks inside a panel right-looking with three launches each (0) or
+    left-looking with the update fused into the factor / row-solve launch, for the factorisation (bit 0) and the
+    right-hand-side rows (bit 1) -- predictions, LOOCV and a not-positive-definite index against the oracle."""
+    from sif_xco2_cokriging_amd import synth
+    pb = synth.conus_problem(1500, seed=12)
+    pc = pb["pcoords"][::13][:500]
+    h = _handle(pb, options={"panel_fused": fused})
+    try:
+        p = orc.Params.from_flat(pb["params"])
+        pred, err = h.predict(0, pc)
+        rp, re = orc.joint_predict(p, pb["coords"], pb["values"], pc, 0, pb["metric"])
+        assert rel(pred, rp) < 1e-8
+        assert np.max(np.abs(err ** 2 - re ** 2)) < 1e-9
+        cp, ce = h.loocv(1, 1500)
+        for ix in (3, 1499):
+            op, oe = orc.joint_predict(p, pb["coords"], pb["values"], pb["coords"][1][ix], 1, pb["metric"], cv_ix=ix)
+            assert abs(cp[ix] - op[0]) < 1e-8 * max(1.0, abs(op[0])) and abs(ce[ix] ** 2 - oe[0] ** 2) < 1e-9
+    finally:
+        h.close()
+
+
 def test_config2_properties_n5000():
     """BASELINE config 2: n_obs = 5k per process on the unit square, 100 x 100 grid, Euclidean."""
     from sif_xco2_cokriging_amd import synth
