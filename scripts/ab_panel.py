@@ -1,5 +1,6 @@
 """A/B of the panel step inside one process: option panel_fused 0 (potrf64 / trsm64m / K = 64 updates, right-looking)
-against 1 (left-looking sub-blocks, two fused launches each).  usage: ab_panel.py [n_obs]"""
+against its fused left-looking forms (bit 0: factorisation, bit 1: right-hand-side rows).
+usage: ab_panel.py [n_obs] [values, default 0,2]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +11,7 @@ pb = synth.conus_problem(n)
 pv = pb["params"]
 res = {}
 for rep in range(2):
-    for fused in (0, 1):
+    for fused in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2").split(",")]:
         h = native.Handle(0)
         h.set_option("panel_fused", fused)
         h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
@@ -28,4 +29,5 @@ for rep in range(2):
         print(json.dumps({"panel_fused": fused, "rep": rep, "factor_ms": t["factor_ms"], "solve_ms": t["solve_ms"],
                           "wall_ms": 1e3 * dt}), flush=True)
         del h
-print("max |pred diff|", float(np.max(np.abs(res[0][0] - res[1][0]))), "max |err diff|", float(np.max(np.abs(res[0][1] - res[1][1]))))
+ks = sorted(res)
+print("max |pred diff|", float(np.max(np.abs(res[ks[0]][0] - res[ks[-1]][0]))), "max |err diff|", float(np.max(np.abs(res[ks[0]][1] - res[ks[-1]][1]))))

@@ -135,7 +135,7 @@ struct ck_handle {
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
     int panel_fused = 2;              // option "panel_fused", bit 0: factorisation, bit 1: right-hand-side rows --
                                       // left-looking 64-column sub-blocks inside a panel, fused launches (measured at
-                                      // N = 40 000: solve sweep 228.9 -> 222.2 ms, factorisation 362.9 -> 365.0 ms)
+                                      // N = 40 000: solve sweep 228.2 -> 219.6 ms, factorisation 362.9 -> 365.0 ms)
     int64_t loo_g0 = -1;              // >= 0 during ck_loocv: right-hand-side row 1 + p is the unit vector of site loo_g0 + p
     double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
@@ -793,8 +793,7 @@ static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
     const double* tail = P + (h->Npad - (int64_t)K * CK_NB) * CK_NB;
     const int64_t rows = aux_rows(h, K);
     if (h->panel_fused & 2) {
-        for (int q = 0; q < CK_NB / CK_IB; ++q)
-            ck_launch_panel_rows(st, X, 0, rows, P, q, tail + (int64_t)q * CK_IB * CK_IB);
+        ck_launch_panel_rows_all(st, X, rows, P, tail);
         return;
     }
     for (int q = 0; q < CK_NB / CK_IB; ++q) {

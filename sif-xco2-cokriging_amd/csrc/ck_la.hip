@@ -1319,6 +1319,28 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows(double* X, long row_first
     lt_rows_body<true>(X + row0 * CK_NB + jb, X + row0 * CK_NB, CK_NB, P + (long)jb * CK_NB, CK_NB, j, Linv, As, Bs);
 }
 
+// all eight sub-blocks of a panel for 64 right-hand-side rows: those rows depend on nothing but the factored
+// panel, so one workgroup can walk through the panel on its own (one launch per panel instead of eight).
+// tail: the eight 64 x 64 inverses behind the panel's rows.
+__global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const double* P, const double* tail) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    const long row0 = 64 * (long)blockIdx.x;
+    for (int j = 0; j < CK_NB / 64; ++j) {
+        if (j) {   // sub-block j reads what other threads of this workgroup stored in sub-blocks < j
+            __threadfence_block();
+            __syncthreads();
+        }
+        lt_rows_body<true>(X + row0 * CK_NB + 64 * j, X + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
+                           tail + (long)j * 64 * 64, As, Bs);
+    }
+}
+
+void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail) {
+    if (nrows <= 0) return;
+    k_panel_rows_all<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(X, P, tail);
+}
+
 void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv) {
     k_panel_diag<<<dim3(1), dim3(256), 0, s>>>(P, j, g0, info, Linv);
 }
