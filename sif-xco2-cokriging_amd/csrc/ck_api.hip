@@ -639,11 +639,12 @@ static int64_t external_index(const ck_handle* h, int64_t g) { return g > h->n0p
 extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
+    HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     bool fast_done = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
-        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        if (attempt) HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
         {
             CkPanelMap pm{h->d_tile0, h->d_panel_of, h->d_sigptr, h->n_owned, nullptr, 0};
             ck_launch_assemble_sigma(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0, h->su,
