@@ -1,6 +1,6 @@
 """A/B of the panel step inside one process: option panel_fused 0 (potrf64 / trsm64m / K = 64 updates, right-looking)
 against its fused left-looking forms (bit 0: factorisation, bit 1: right-hand-side rows).
-usage: ab_panel.py [n_obs] [values, default 0,2]"""
+usage: ab_panel.py [n_obs] [values, default 0,2] [option name, default panel_fused]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,7 @@ res = {}
 for rep in range(2):
     for fused in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2").split(",")]:
         h = native.Handle(0)
-        h.set_option("panel_fused", fused)
+        h.set_option(sys.argv[3] if len(sys.argv) > 3 else "panel_fused", fused)
         h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
         h.set_metric(0)
         for k in range(2):
