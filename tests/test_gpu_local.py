@@ -195,3 +195,35 @@ def test_predictor_call_signature_and_warnings():
     cv = P.cross_validation(0, max_dist=700.0, postprocess=False)
     assert list(cv.columns) == ["d1", "d2", "data", "pred", "residual", "pred_err"]
     assert len(cv) == 200
+
+
+@pytest.mark.parametrize("tile_min", [0, None])
+def test_local_system_sizes_around_the_padding_boundaries(tile_min):
+    """max_dist = infinity makes every neighbourhood the whole data set, so the local system has exactly
+    k = n0 + n1 sites: sizes around the tiled path's padding boundaries (k + 2 a multiple of 64: no identity
+    padding at all; k + 2 one more: a whole block of it), around the LDS kernel's limit of 64, and two- / three-site
+    systems."""
+    from sif_xco2_cokriging_amd import native, synth
+    from oracle import cokrige_oracle as orc
+    pb = synth.conus_problem(120, seed=41)
+    pv = pb["params"]
+    op = orc.Params.from_flat(pv)
+    pc = pb["pcoords"][::797][:9]
+    for n0, n1 in [(1, 1), (2, 1), (30, 31), (31, 31), (32, 31), (32, 32), (33, 32), (63, 63), (64, 63),
+                   (64, 64), (65, 64), (100, 90), (100, 91), (120, 7)]:
+        coords = [pb["coords"][0][:n0], pb["coords"][1][:n1]]
+        values = [pb["values"][0][:n0], pb["values"][1][:n1]]
+        h = native.Handle(0)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(0)
+        for k in range(2):
+            h.set_data(k, coords[k], values[k])
+        if tile_min is not None:
+            h.set_option("local_tile_min", tile_min)
+        for i in (0, 1):
+            pred, err, info = h.predict_local(i, pc, max_dist=1e9)
+            assert info["k_max"] == n0 + n1 and info["n_not_pd"] == 0, (n0, n1, info)
+            rp, re = orc.local_predict(op, coords, values, pc, i, 0, 1e9)[:2]
+            np.testing.assert_allclose(pred, rp, rtol=1e-8, atol=1e-10, err_msg=f"n0={n0} n1={n1} i={i}")
+            np.testing.assert_allclose(err ** 2, re ** 2, rtol=1e-8, atol=1e-10, err_msg=f"n0={n0} n1={n1} i={i}")
+        h.close()
