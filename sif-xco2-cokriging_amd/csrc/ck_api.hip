@@ -108,6 +108,7 @@ struct ck_handle {
     // empirical variogram state (ck_vario_*)
     std::vector<double> vg_ci, vg_cj;   // host copies of the coordinates (extreme pairs are re-evaluated)
     double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
+    unsigned long long* vg_best = nullptr;       // extreme-pair hints of the extent pass (ck_vario.hip)
     double *vg_ib = nullptr, *vg_jb = nullptr;   // bounding balls of the pair tiles' point blocks (ck_vario.hip)
     int64_t vg_ni = 0, vg_nj = 0;
     int vg_same = 0, vg_grid = 0;
@@ -1454,11 +1455,12 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {
     void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
-                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut, h->vg_ib, h->vg_jb};
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut, h->vg_ib, h->vg_jb, h->vg_best};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
     h->vg_ib = h->vg_jb = nullptr;
+    h->vg_best = nullptr;
     h->vg_part = nullptr;
     h->vg_psum = nullptr;
     h->vg_pcnt = nullptr;
@@ -1525,6 +1527,7 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
     }
     HIPCHK(hipMalloc((void**)&h->vg_ib, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 0) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_best, 16));
     ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 0, h->vg_ib);
     ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1, h->vg_jb);
     HIPCHK(hipGetLastError());
@@ -1551,7 +1554,7 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     if (!h->vg_iu) return fail("ck_vario_begin has not been called");
     const double rcap = vario_r_of_dist(h->metric, max_dist);
     ck_launch_vario_extent(h->stream, h->vg_grid, h->metric, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj,
-                           rcap, h->vg_part, h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(h->metric, rcap));
+                           rcap, h->vg_part, h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(h->metric, rcap), h->vg_best);
     HIPCHK(hipGetLastError());
     std::vector<CkVarioExt> part(h->vg_grid);
     HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost,

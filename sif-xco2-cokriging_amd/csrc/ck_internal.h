@@ -121,7 +121,7 @@ int ck_vario_grid(int64_t ni, int64_t nj);
 // iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]
 void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
                             const double* ju, int64_t nj, double rcap, void* part, int rank, int world,
-                            const double* ib, const double* jb, double cmax);
+                            const double* ib, const double* jb, double cmax, unsigned long long* best /* 2 words */);
 // tile culling (ck_vario.hip): bounding balls of the 256-point "i" blocks / 1024-point "j" chunks, 4 x nblk doubles;
 // cmax = largest chord |u_i - u_j| of a retained pair (with margin); ib == nullptr switches the culling off
 int64_t ck_vario_nblocks(int64_t n, int j_side);

@@ -132,7 +132,13 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
                                                           const double* __restrict__ ju2, long nj, double rcap,
                                                           VarioPartialExt* __restrict__ part, int rank, int world,
                                                           const double* __restrict__ ib, const double* __restrict__ jb,
-                                                          double cmax) {
+                                                          double cmax, unsigned long long* best) {
+    // best[0]: bit pattern of the largest retained r any workgroup has seen so far, best[1]: of the smallest
+    // positive one (non-negative doubles order like their bit patterns).  A tile whose bounding balls say that all
+    // its pairs lie strictly inside (rlo, rhi) with rhi < best[0] and rlo > best[1] cannot change either extreme
+    // and is skipped; a stale hint only makes the test more conservative.  Nine tiles in ten go this way once the
+    // first wave of workgroups has reported: the largest retained lag sits in the tiles that straddle max_dist,
+    // the smallest positive one in tiles whose balls touch.
     __shared__ double red_r[VG_TPB];
     __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
     const int tid = threadIdx.x;
@@ -144,7 +150,17 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
         if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
-        if (vario_tile_far(ib, nI, bi, jb, nJ, bj, cmax)) continue;   // no pair of this tile within max_dist
+        if (ib) {
+            const double dx = ib[bi] - jb[bj], dy = ib[nI + bi] - jb[nJ + bj], dz = ib[2 * nI + bi] - jb[2 * nJ + bj];
+            const double dc = sqrt(dx * dx + dy * dy + dz * dz), rr = ib[3 * nI + bi] + jb[3 * nJ + bj];
+            if (dc - rr > cmax) continue;   // no pair of this tile within max_dist
+            const double sc = metric == CK_METRIC_HAVERSINE ? 0.25 : 1.0;
+            const double lo1 = fmax(dc - rr, 0.0) * (1.0 - 1e-9), hi1 = (dc + rr) * (1.0 + 1e-9) + 1e-12;
+            const double rlo = sc * lo1 * lo1 * (1.0 - 1e-12), rhi = fmin(sc * hi1 * hi1 * (1.0 + 1e-12), rcap);
+            const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
+            const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
+            if (rhi < bmax && rlo > bmin) continue;   // cannot hold a new extreme (uniform: same loads for all lanes)
+        }
         const long i = i0 + tid;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
@@ -167,6 +183,17 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int metric, int same, c
                     imin = i;
                     jmin = j0 + k;
                 }
+            }
+        }
+        if (ib) {   // publish this wave's extremes so far: hints for every workgroup's tile test above
+            double wmax = rmax, wmin = rmin;
+            for (int off = 32; off > 0; off >>= 1) {
+                wmax = fmax(wmax, __shfl_xor(wmax, off));
+                wmin = fmin(wmin, __shfl_xor(wmin, off));
+            }
+            if ((tid & 63) == 0) {
+                if (wmax > 0.0) atomicMax(&best[0], (unsigned long long)__double_as_longlong(wmax));
+                if (wmin < 1e300) atomicMin(&best[1], (unsigned long long)__double_as_longlong(wmin));
             }
         }
     }
@@ -412,10 +439,14 @@ int ck_vario_grid(int64_t ni, int64_t nj) {
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
                             const double* ju, int64_t nj, double rcap, void* part, int rank, int world,
-                            const double* ib, const double* jb, double cmax) {
+                            const double* ib, const double* jb, double cmax, unsigned long long* best) {
+    // best: two words of device memory, initialised here to "nothing seen yet" (largest retained r = 0.0, smallest
+    // positive r = the largest finite double)
+    static const unsigned long long init[2] = {0ULL, 0x7fefffffffffffffULL};
+    (void)hipMemcpyAsync(best, init, sizeof(init), hipMemcpyHostToDevice, s);
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(metric, same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj,
                                                        ju + 2 * nj, nj, rcap, (VarioPartialExt*)part, rank, world, ib, jb,
-                                                       cmax);
+                                                       cmax, best);
 }
 
 // bounding balls of the "i" blocks (VG_TPB points) or the "j" chunks (VG_JCHUNK points): 4 x nblk doubles
