@@ -331,6 +331,27 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
             atomicAdd(&hcnt[bb][tid], keep ? 1u : 0u);                                                          \
         }                                                                                                       \
     }
+    // ... and for an INTERIOR tile: every pair is retained (the balls say r <= min(rcap, rtop) for all of them, the
+    // chunk lies strictly above the diagonal, all 256 "i" lanes are live) -- no per-pair conditions at all.
+#define VG_GROUP8I                                                                                              \
+    {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < VG_G; ++u) {                                                         \
+            const long kk = kg + u;                                                                             \
+            const double r = pair_r(metric, ax, ay, az, ju0[j0 + kk], ju1[j0 + kk], ju2[j0 + kk]);              \
+            const double bvu = jv[j0 + kk];                                                                     \
+            int b = wb;                                                                                         \
+            _Pragma("unroll") for (int w = 0; w < VG_W - 1; ++w) b += (r > wt[w]) ? 1 : 0;                         \
+            double cl;                                                                                          \
+            if (covariogram) {                                                                                  \
+                cl = av * bvu;                                                                                  \
+            } else {                                                                                            \
+                const double df = av - bvu;                                                                     \
+                cl = 0.5 * (df * df);                                                                           \
+            }                                                                                                   \
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&hsum[b][tid], cl);  \
+            atomicAdd(&hcnt[b][tid], 1u);                                                                       \
+        }                                                                                                       \
+    }
     const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     // per-lane 64-bit count spill: hcnt is 32-bit, a lane sees at most nJ * VG_JCHUNK pairs per I block
     // tile list sharded over processes (ck_set_partition): this one takes the tiles t = rank (mod world)
@@ -350,6 +371,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
         // bin window of the tile (margins far above the rounding of either side): every pair has
         // wb <= bin <= wbhi; the fast group needs the window to fit VG_W bins
         int wb = 0, wbhi = nb - 1;
+        bool all_in = false;   // every pair of the tile within max_dist and the last edge
         if (ib) {
             const double sc = metric == CK_METRIC_HAVERSINE ? 0.25 : 1.0;
             const double lo1 = fmax(dlo, 0.0) * (1.0 - 1e-9), hi1 = dhi * (1.0 + 1e-9) + 1e-12;
@@ -359,8 +381,10 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
                 wb += (rlo > sthr[e]) ? 1 : 0;
                 wbhi += (rhi > sthr[e]) ? 1 : 0;
             }
+            all_in = rhi <= rcap && rhi <= rtop;
         }
         const bool narrow = ib && wbhi - wb < VG_W;
+        bool interior = false;   // set below, once the tile's extent in i and j is known
         double wt[VG_W - 1];   // the window's inner edges thr[wb + 1 ..], +inf beyond the last bin
 #pragma unroll
         for (int w = 0; w < VG_W - 1; ++w) wt[w] = (wb + 1 + w < nb) ? sthr[wb + 1 + w] : 1e300;
@@ -384,7 +408,11 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
         // ds_add_u32): sequential per lane in program order, hence deterministic; pairs that are not
         // retained add 0 to a trash row (index nb).
         long kg = k0;
-        if (narrow) {
+        interior = narrow && all_in && i0 + VG_TPB <= ni && (!same || j0 >= i0 + VG_TPB);
+        if (interior) {
+            for (; kg + VG_G <= jend; kg += VG_G) VG_GROUP8I;
+            for (; kg < jend; kg += VG_G) VG_GROUP8W(false);
+        } else if (narrow) {
             for (; kg + VG_G <= jend; kg += VG_G) VG_GROUP8W(true);
             for (; kg < jend; kg += VG_G) VG_GROUP8W(false);
         } else {
@@ -395,6 +423,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(int metric, int same, int 
     }
 #undef VG_GROUP8
 #undef VG_GROUP8W
+#undef VG_GROUP8I
     __syncthreads();
     // reduce the 256 private histograms: thread b sums bin b in lane order (deterministic)
     if (tid < nb) {
