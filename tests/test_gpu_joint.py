@@ -419,3 +419,46 @@ def test_parity_in_units_of_the_oracles_own_perturbation_floor(native, tag):
     e = rel(pred, ref)
     print(f"set {tag}: cond(Sigma) = {cond:.3g}, oracle 1-ulp floor = {floor:.2e}, HIP vs oracle = {e:.2e}")
     assert e < 1e-9 and e < 200.0 * floor + 1e-13
+
+
+def _hilbert_keys(xy, lo, hi):
+    """numpy restatement of the library's order-16 Hilbert key (csrc/ck_api.hip: hilbert_key / hilbert_order)."""
+    s = np.where(hi > lo, 65536.0 / np.where(hi > lo, hi - lo, 1.0), 0.0)
+    f = np.clip((xy - lo) * s, 0.0, 65535.0)
+    x, y = f[:, 0].astype(np.uint64), f[:, 1].astype(np.uint64)
+    d = np.zeros(len(xy), dtype=np.uint64)
+    lvl = 32768
+    while lvl > 0:
+        rx = ((x & np.uint64(lvl)) != 0).astype(np.uint64)
+        ry = ((y & np.uint64(lvl)) != 0).astype(np.uint64)
+        d += np.uint64(lvl) * np.uint64(lvl) * ((np.uint64(3) * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, np.uint64(lvl - 1) - x, x)
+        y = np.where(flip, np.uint64(lvl - 1) - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        lvl >>= 1
+    return d
+
+
+@pytest.mark.parametrize("n0", [3000, 9000])   # comparison sort below 4 096 points, threaded keys + radix sort above
+def test_hilbert_site_order_matches_its_definition(native, n0):
+    """The internal site order is the STABLE sort by Hilbert key (coincident sites and equal keys keep the caller's
+    order): both host implementations against a numpy restatement, with duplicated sites in the data."""
+    rng = np.random.default_rng(8)
+    c0 = np.column_stack([rng.uniform(25, 50, n0), rng.uniform(-120, -70, n0)])
+    c0[n0 // 2: n0 // 2 + 200] = c0[:200]                 # coincident sites
+    c0[-50:] = np.round(c0[-50:], 1)                      # a coarse lattice: more equal keys
+    c1 = np.column_stack([rng.uniform(20, 55, 300), rng.uniform(-125, -65, 300)])   # widens the bounding box
+    pv = [0.99, 0.81, 0.39, 0.695, 1.0, 460.0, 460.0, 460.0, 0.02, 0.025, -0.19]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(HAV)
+    h.set_data(0, c0, np.zeros(n0))
+    h.set_data(1, c1, np.zeros(300))
+    allc = np.vstack([c0, c1])
+    lo, hi = allc.min(axis=0), allc.max(axis=0)
+    for k, c in ((0, c0), (1, c1)):
+        ref = np.argsort(_hilbert_keys(c, lo, hi), kind="stable")
+        assert np.array_equal(h.debug_site_order(k, len(c)), ref)
+    h.close()
