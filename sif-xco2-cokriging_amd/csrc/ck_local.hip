@@ -524,6 +524,13 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
 // ---------------------------------------------------------------------------------------
 // tiled path (ck_internal.h: CkLocalSys; the factorisation steps are in ck_la.hip)
 // ---------------------------------------------------------------------------------------
+// the exact formulas as an out-of-line call: rare in the table kernel below, and out of line it does not inflate
+// its registers
+__device__ __noinline__ double lp_exact_pair(const CkMatern* m, int metric, int nug, const double* s0, const double* s1,
+                                             const double* s2, long ga, long gb) {
+    return ck_cov_entry(*m, lp_dist(metric, s0[ga], s1[ga], s2[ga], s0[gb], s1[gb], s2[gb]), nug);
+}
+
 // Neighbour lists and padded local systems of a batch.
 // k_local_search_t (one workgroup per system): the neighbour list, the number k0 of process-0 neighbours, the
 // identity padding, the zeros the 64 x 64 factorisation expects above the diagonal, the c and z rows.
@@ -534,7 +541,8 @@ void ck_launch_local_solve(hipStream_t s, const CkMatern* blk, int metric, int i
 // LT_BC columns and LT_AC rows staged in LDS, a thread takes one column of four rows at a time (four
 // independent Horner chains), writes run along rows.  Entries outside the table (coincident sites, pairs beyond
 // its range) and everything when the tables are off go through the exact evaluator in a second, rolled loop.
-#define LT_BC 1024
+#define LT_BC 512
+#define LT_WL 1024   // deferred exact pairs per system and block (LDS list; beyond that they are evaluated in place)
 #define LT_AC 256
 #define LT_TPB 512   // 8 waves: with two workgroups per CU (LDS) four waves per SIMD hide the table-read latency
 __global__ __launch_bounds__(LP_TPB) void k_local_search_t(const CkMatern* __restrict__ blk, int metric, int i_pred, int cv,
@@ -609,6 +617,8 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
     __shared__ double tab[(CK_TAB_DEG + 1) * CK_TAB_STRIDE];
     __shared__ double bu[3][LT_BC];
     __shared__ double au[3][LT_AC];
+    __shared__ int2 wl[LT_WL];   // (row, column) of entries the table does not cover: evaluated one pair per LANE after
+    __shared__ int wl_n;         // the system's region is done, instead of one pair per WAVE where they are found
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *s0 = sc, *s1 = sc + L.npad, *s2 = sc + 2 * L.npad;
     const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
         const int alo = reg == 0 ? 0 : k0, ahi = reg == 0 ? k0 : k;
         const int blo = reg == 2 ? k0 : 0, bhi = reg == 2 ? k : k0;
         if (alo >= ahi || blo >= bhi) continue;   // uniform
+        if (tid == 0) wl_n = 0;   // (ordered against the appends by the barrier at the top of the chunk loop)
         for (int bc = blo; bc < bhi; bc += LT_BC) {
             const int nbc = min(LT_BC, bhi - bc);
             __syncthreads();
@@ -701,20 +712,27 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
                             }
                         }
                         if (need) {
-                            const long gb = idx[b];
-                            const double e0 = s0[gb], e1 = s1[gb], e2 = s2[gb];
 #pragma unroll 1
                             for (int r = 0; r < 4; ++r)
                                 if (need >> r & 1u) {
                                     const int a = ac + r0 + r;
-                                    const long ga = idx[a];
-                                    S[(long)a * ld + b] =
-                                        ck_cov_entry(blk[reg], lp_dist(metric, s0[ga], s1[ga], s2[ga], e0, e1, e2), nug);
+                                    const int slot = atomicAdd(&wl_n, 1);
+                                    if (slot < LT_WL) {
+                                        wl[slot] = make_int2(a, b);
+                                    } else {   // list full: in place
+                                        S[(long)a * ld + b] = lp_exact_pair(&blk[reg], metric, nug, s0, s1, s2, idx[a], idx[b]);
+                                    }
                                 }
                         }
                     }
                 }
             }
+        }
+        __syncthreads();
+        const int nw = min(wl_n, LT_WL);
+        for (int e = tid; e < nw; e += LT_TPB) {
+            const int a = wl[e].x, b = wl[e].y;
+            S[(long)a * ld + b] = lp_exact_pair(&blk[reg], metric, nug, s0, s1, s2, idx[a], idx[b]);
         }
     }
 }
