@@ -46,6 +46,12 @@ struct LpTab {
     int use;
 };
 
+// the exact formulas out of line: rare beside the table, and inlined they cost the callers their registers
+__device__ __noinline__ double lp_exact_xyz(const CkMatern* m, int metric, int nug, double a0, double a1, double a2,
+                                            double b0, double b1, double b2) {
+    return ck_cov_entry(*m, lp_dist(metric, a0, a1, a2, b0, b1, b2), nug);
+}
+
 __device__ __forceinline__ double lp_cov(const CkMatern* blk, const LpTab& T, int bidx, int nug, int metric, double a0,
                                          double a1, double a2, double au0, double au1, double au2, double b0, double b1,
                                          double b2, double bu0, double bu1, double bu2) {
@@ -56,7 +62,7 @@ __device__ __forceinline__ double lp_cov(const CkMatern* blk, const LpTab& T, in
         const double y = ck_table_y(q, &iv, T.tabs[bidx].base);
         if ((unsigned)iv < (unsigned)T.tabs[bidx].n_int) return ck_table_poly(T.coefs[bidx], iv, y);
     }
-    return ck_cov_entry(blk[bidx], lp_dist(metric, a0, a1, a2, b0, b1, b2), nug);
+    return lp_exact_xyz(&blk[bidx], metric, nug, a0, a1, a2, b0, b1, b2);
 }
 
 // Radius search with chunk culling: the sites are laid out along a Hilbert curve (ck_api.hip: site_order), so
