@@ -152,6 +152,7 @@ def main():
         from sif_xco2_cokriging_amd import distributed
         runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank))
         runner.prepare(m_total=m)
+        h.set_option("time_gemm", 2)   # HIP events around this rank's Sigma trailing-update launches
 
         def step():
             return runner.predict(0, pb["pcoords"])
@@ -198,6 +199,20 @@ def main():
                                     f"Matern set {args.params}"),
                        "n_obs": n, "N": N, "m": m, "params": pv, "partition": f"block-column-cyclic x{world}"},
         }
+        if world > 1 and tim[-1]["syrk_launches"] > 0:
+            # rank 0's share of the trailing updates: block column J (owned if J % world == 0) receives J panels
+            nK = -(-N // 512)
+            Npad = nK * 512
+            flops = sum(J * ((Npad - J * 512) * 512 - 512 * 511 / 2) * 2 * 512 for J in range(0, nK, world))
+            tl = tim[-1]
+            syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
+            out["roofline"] = {
+                "kernel": "k_syrk_group_d on rank 0 (one panel per launch in the multi-GPU form: K = 512, the owned block columns)",
+                "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
+                "algorithmic_flops_per_step": flops,
+            }
         if world == 1:
             tl = tim[-1]
             flops = trailing_update_flops(N)

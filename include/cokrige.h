@@ -208,7 +208,8 @@ int ck_table_info(ck_handle* h, int block, int* enabled, int* n_intervals, doubl
 /* Entries the table path deferred to the exact evaluator (pairs closer than the table's lower end
  * or beyond its upper end) in this handle's assemblies since the last reset. */
 int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
-/* Options: "time_gemm" (0/1) brackets every trailing-update launch with HIP events;
+/* Options: "time_gemm" (0/1/2) brackets every trailing-update launch with HIP events (2: the Sigma updates only, for
+ * the step-wise form, where Sigma and right-hand-side updates alternate; read back through ck_timings);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);

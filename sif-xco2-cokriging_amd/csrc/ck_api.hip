@@ -119,7 +119,7 @@ struct ck_handle {
     unsigned char* vg_lut = nullptr;
     // timings
     double t_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool time_gemm = false;
+    int time_gemm = 0;   // 1: bracket every trailing-update launch with events | 2: the Sigma updates only (step-wise form)
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -848,6 +848,7 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     if (nJ <= 0) return;
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     const int64_t rows = aux_rows(h, K);
+    timed = timed && h->time_gemm == 1;   // 2: only the Sigma updates are timed (one event list per sweep)
     if (timed) gemm_timed_begin(h, st);
     if (h->gemm_variant == 7 || h->gemm_variant == 8)
         ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, h->gemm_variant, rows);
@@ -1133,6 +1134,7 @@ extern "C" int ck_aux_finish(ck_handle* h, double* pred, double* pred_err) {
         HIPCHK(hipMemcpyAsync(pred_err, h->d_err, h->m * 8, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->time_gemm == 2) gemm_timed_collect(h, 5);   // step-wise form: the Sigma updates of this sweep
     if (h->m > 0 && h->p_sorted) {   // back to the caller's order
         std::vector<double> tp((size_t)h->m), te((size_t)h->m);
         HIPCHK(hipMemcpyAsync(tp.data(), h->d_pred, h->m * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1771,7 +1773,8 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     CHKH(h);
     if (!name) return fail("null option name");
     if (!strcmp(name, "time_gemm")) {
-        h->time_gemm = value != 0;
+        if (value < 0 || value > 2) return fail("time_gemm must be 0, 1 or 2");
+        h->time_gemm = (int)value;
         return 0;
     }
     if (!strcmp(name, "gemm_variant")) {   // A/B switch of the GEMM tile structure (this handle)
