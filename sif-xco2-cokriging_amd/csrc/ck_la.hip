@@ -1027,6 +1027,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
             }
     }
     __syncthreads();
+    if (!Linv) return;   // uniform: a diagonal block with no rows below it (the last block of a local system)
     // ---- the inverse, blocked 4 x 4 in 16 x 16 blocks ----
     // A. the four diagonal blocks: wave b inverts D_b, lane r < 16 solving for column r of its inverse by
     //    right-looking substitution (16 steps, multipliers broadcast from Lt);
@@ -1272,7 +1273,8 @@ __global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict
         lt_diag_update(S, q.ld, g0, i, &M[0][0]);
         __syncthreads();   // the block is re-read from memory by other threads of this workgroup
     }
-    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x, S + (long)CK_LT_ROWS(q.kq) * q.ld, M, M);
+    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x,
+                 jb + 64 < q.kq ? S + (long)CK_LT_ROWS(q.kq) * q.ld : nullptr, M, M);
 }
 
 // rows below the diagonal block: in-group update and row solve
