@@ -174,6 +174,17 @@ int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64
 int ck_vario_bin(ck_handle* h, double max_dist, const double* edges_host, int n_edges, int covariogram,
                  double* sums_host, int64_t* counts_host);
 int ck_vario_end(ck_handle* h);
+/* Counters of the last ck_vario_extent / ck_vario_bin: [0] pairs of the extent pass decided on the host,
+ * [1] pairs of the binning pass decided on the host, [2] pairs the binning pass visited (tiles that cannot hold a
+ * retained pair are skipped), [3] extra rounds of the extent pass. */
+int ck_vario_stats(ck_handle* h, int64_t* out4, int n);
+/* How the variogram passes decide ties.  The reference decides on the rounded distance d (`d <= max_dist`, pd.cut on
+ * the edges: src/fields.py:212-216); the kernels compare a monotone function of d and hand every pair within the
+ * rounding band of a threshold to the reference's own formula: Euclidean on the device (bit-identical to scipy's
+ * cdist), haversine on the host through libm -- bit for bit sklearn's haversine_distances(np.radians(X)) * 6371
+ * (src/fields.py:332-336), which device trigonometry is not.  That host function, for n coordinate pairs
+ * (A, B: n x 2), no GPU needed: */
+int ck_ref_distance(int metric, const double* A_host, const double* B_host, int64_t n, double* out_host);
 
 /* ---- diagnostics ------------------------------------------------------------- */
 /* Copy the locally owned part of Sigma / L back as a dense (N x N) lower triangle

@@ -25,9 +25,12 @@ else:
     pairs = n * (n - 1) // 2
 dt = time.perf_counter() - t0
 tb = h.timings()["vario_bin_ms"]
+st = h.vario_stats()
 print(json.dumps({"workload": f"config 5: {'cross-' if cross else ''}semivariogram, {n} soundings, max_dist 1500 km, 30 bins",
                   "pairs": pairs, "retained_pairs": int(counts.sum()), "wall_s": dt, "bin_pass_ms": tb,
                   "pairs_per_s_wall": pairs / dt, "pairs_per_s_bin_pass": pairs / (tb / 1e3),
+                  "visited_pairs": st["bin_visited_pairs"], "visited_pairs_per_s_bin_pass": st["bin_visited_pairs"] / (tb / 1e3),
+                  "host_decided_pairs": [st["extent_host_pairs"], st["bin_host_pairs"]], "extent_extra_rounds": st["extent_extra_rounds"],
                   "bin_mean_first3": means[:3].tolist(), "bin_count_first3": counts[:3].tolist()}))
 if "cpu" in sys.argv[2:]:
     # the reference's dense-matrix path (oracle restatement) on this box's host cores, bounded sample

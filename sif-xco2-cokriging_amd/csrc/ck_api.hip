@@ -106,17 +106,23 @@ struct ck_handle {
     double *d_pred = nullptr, *d_err = nullptr;
     double* d_pcoords = nullptr;
     // empirical variogram state (ck_vario_*)
-    std::vector<double> vg_ci, vg_cj;   // host copies of the coordinates (extreme pairs are re-evaluated)
+    std::vector<double> vg_ci, vg_cj, vg_vi, vg_vj;   // host copies of coordinates / residuals in the device's point order
+                                                      // (the pairs the kernels leave to the host are decided on these)
     double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
     unsigned long long* vg_best = nullptr;       // extreme-pair hints of the extent pass (ck_vario.hip)
-    double *vg_ib = nullptr, *vg_jb = nullptr;   // bounding balls of the pair tiles' point blocks (ck_vario.hip)
+    double *vg_ib = nullptr, *vg_jb = nullptr;   // bounding balls: 256-point "i" blocks, 1024-point "j" chunks
+    double *vg_ib64 = nullptr, *vg_jb256 = nullptr;   // ... and of the binning pass's wave tiles / sub-chunks
     int64_t vg_ni = 0, vg_nj = 0;
-    int vg_same = 0, vg_grid = 0;
+    int vg_same = 0, vg_grid = 0, vg_bgrid = 0;
     void* vg_part = nullptr;
     double* vg_psum = nullptr;
     unsigned long long* vg_pcnt = nullptr;
-    double* vg_out = nullptr;          // thr[38] | sums[36] | counts[36] (as 8-byte words)
-    unsigned char* vg_lut = nullptr;
+    double* vg_out = nullptr;          // thi[38] | dthr[38] | sums[36] | counts[37] (8-byte words)
+    CkVarioPair* vg_list = nullptr;    // pairs left to the host
+    unsigned* vg_count = nullptr;
+    unsigned vg_list_cap = 0;
+    int64_t vg_stats[4] = {0, 0, 0, 0};   // host-decided pairs of the extent pass | of the binning pass | pairs visited by
+                                          // the binning pass | extra extent rounds
     // timings
     double t_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int time_gemm = 0;   // 1: bracket every trailing-update launch with events | 2: the Sigma updates only (step-wise form)
@@ -1457,27 +1463,30 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {
     void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
-                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_lut, h->vg_ib, h->vg_jb, h->vg_best};
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_ib, h->vg_jb, h->vg_ib64, h->vg_jb256,
+                  h->vg_best, h->vg_list, h->vg_count};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
-    h->vg_ib = h->vg_jb = nullptr;
+    h->vg_ib = h->vg_jb = h->vg_ib64 = h->vg_jb256 = nullptr;
     h->vg_best = nullptr;
     h->vg_part = nullptr;
     h->vg_psum = nullptr;
     h->vg_pcnt = nullptr;
     h->vg_out = nullptr;
-    h->vg_lut = nullptr;
+    h->vg_list = nullptr;
+    h->vg_count = nullptr;
+    h->vg_list_cap = 0;
 }
 
 // Upload one field's points.  From 2 048 points on (and unless site_order = 0) they are first laid out along a
 // Hilbert curve: bins sums and counts do not depend on the order of the points (up to rounding of the sums), and
 // compact blocks of points are what lets the kernels skip whole pair tiles (ck_vario.hip, "tile culling").
-// host_coords receives the coordinates in the order the device sees them (the extreme pairs come back as indices).
+// host_coords / host_vals receive the points in the order the device sees them (pairs come back as indices).
 static int vario_upload(ck_handle* h, const double* coords, const double* vals, int64_t n, double** u, double** v,
-                        std::vector<double>& host_coords) {
+                        std::vector<double>& host_coords, std::vector<double>& host_vals) {
     host_coords.assign(coords, coords + 2 * n);
-    std::vector<double> hv(vals, vals + n);
+    host_vals.assign(vals, vals + n);
     if (h->site_order && n >= 2048) {
         double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
         bounding_box(coords, n, lo, hi);
@@ -1487,7 +1496,7 @@ static int vario_upload(ck_handle* h, const double* coords, const double* vals, 
             const int64_t e = perm[(size_t)k];
             host_coords[2 * k] = coords[2 * e];
             host_coords[2 * k + 1] = coords[2 * e + 1];
-            hv[(size_t)k] = vals[e];
+            host_vals[(size_t)k] = vals[e];
         }
     }
     double* tmp = nullptr;
@@ -1495,17 +1504,61 @@ static int vario_upload(ck_handle* h, const double* coords, const double* vals, 
     HIPCHK(hipMalloc((void**)v, n * 8));
     HIPCHK(hipMalloc((void**)&tmp, 2 * n * 8));
     HIPCHK(hipMemcpyAsync(tmp, host_coords.data(), 2 * n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(*v, hv.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(*v, host_vals.data(), n * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_vario_prep(h->stream, tmp, n, h->metric, *u, *u + n, *u + 2 * n);
     HIPCHK(hipStreamSynchronize(h->stream));
     (void)hipFree(tmp);
     return 0;
 }
 
-// largest chord |u_i - u_j| of a pair with r <= rlim, with a safety margin (ck_vario.hip: vario_tile_far)
-static double vario_cmax(int metric, double rlim) {
-    const double c = metric == CK_METRIC_HAVERSINE ? 2.0 * sqrt(rlim) : sqrt(rlim);
-    const double m = c * (1.0 + 1e-9) + 1e-12;
+// The reference's own distance arithmetic, on the host with libm -- bit for bit what src/fields.py:332-342
+// returns: sklearn's haversine_distances (Cython on libm's sin / cos / asin / sqrt) of np.radians(X) times 6371,
+// or scipy's cdist.  The variogram kernels leave every pair whose bin or retention they cannot decide beyond
+// rounding to this function (and the test suite checks it against sklearn / scipy bit by bit on the CPU).
+static double ref_distance(int metric, const double* a, const double* b) {
+#pragma clang fp contract(off)
+    if (metric == CK_METRIC_EUCLID) {
+        const double d0 = a[0] - b[0], d1 = a[1] - b[1];
+        const double s0 = d0 * d0;
+        const double s1 = d1 * d1;
+        return sqrt(s0 + s1);
+    }
+    const double lat1 = a[0] * CK_DEG2RAD, lon1 = a[1] * CK_DEG2RAD, lat2 = b[0] * CK_DEG2RAD, lon2 = b[1] * CK_DEG2RAD;
+    const double sin_0 = sin(0.5 * (lat1 - lat2));
+    const double sin_1 = sin(0.5 * (lon1 - lon2));
+    const double c = cos(lat1) * cos(lat2) * sin_1 * sin_1;
+    const double r = sin_0 * sin_0 + c;
+    const double d = 2 * asin(sqrt(r));
+    return d * CK_EARTH_RADIUS_KM;
+}
+
+extern "C" int ck_ref_distance(int metric, const double* A, const double* B, int64_t n, double* out) {
+    if (metric != CK_METRIC_HAVERSINE && metric != CK_METRIC_EUCLID) return fail("unknown metric");
+    if (n > 0 && (!A || !B || !out)) return fail("null array");
+    for (int64_t k = 0; k < n; ++k) out[k] = ref_distance(metric, A + 2 * k, B + 2 * k);
+    return 0;
+}
+
+// distance -> the monotone q the kernels compare (ck_vario.hip): squared chord of the unit vectors | squared distance
+static double vario_q_of_dist(int metric, double d) {
+    if (!(d >= 0.0)) return 0.0;
+    if (metric == CK_METRIC_EUCLID) return d * d;
+    const long double a = (long double)d / (2.0L * CK_EARTH_RADIUS_KM);
+    if (a >= 1.57079632679489661923L) return 4.0 + 1e-9;   // beyond half the circumference: everything
+    const long double sn = sinl(a);
+    return (double)(4.0L * sn * sn);
+}
+
+// Rounding band of q around a threshold: |q_device - q(d_reference)| stays far inside it.  Haversine: the unit
+// vectors carry ~1e-16 absolute error per component, so q = |u_i - u_j|^2 carries ~2 sqrt(q) 3e-16 (measured
+// 5e-16 sqrt(q) over lattice pairs from 5 km to 6 000 km), and the reference's own d a few ulp; Euclid: a few ulp.
+static double vario_band(int metric, double q) {
+    return metric == CK_METRIC_HAVERSINE ? 6e-15 * sqrt(q) + 8e-15 * q : 8e-15 * q;
+}
+
+// largest chord |u_i - u_j| of a pair with q <= qlim, with a safety margin (ck_vario.hip: tile culling)
+static double vario_cmax(double qlim) {
+    const double m = sqrt(qlim) * (1.0 + 1e-9) + 1e-12;
     return m == m ? m : INFINITY;
 }
 
@@ -1514,80 +1567,159 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
     CHKH(h);
     if (n_i <= 0 || !coords_i || !resid_i) return fail("bad field i");
     if (!same && (n_j <= 0 || !coords_j || !resid_j)) return fail("bad field j");
+    if (n_i >= (1LL << 31) || n_j >= (1LL << 31)) return fail("at most 2^31 - 1 points per field");
     vario_free(h);
     h->vg_same = same ? 1 : 0;
     h->vg_ni = n_i;
-    if (vario_upload(h, coords_i, resid_i, n_i, &h->vg_iu, &h->vg_iv, h->vg_ci)) return -1;
+    if (vario_upload(h, coords_i, resid_i, n_i, &h->vg_iu, &h->vg_iv, h->vg_ci, h->vg_vi)) return -1;
     if (same) {
         h->vg_nj = n_i;
         h->vg_cj = h->vg_ci;
+        h->vg_vj = h->vg_vi;
         h->vg_ju = h->vg_iu;
         h->vg_jv = h->vg_iv;
     } else {
         h->vg_nj = n_j;
-        if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv, h->vg_cj)) return -1;
+        if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv, h->vg_cj, h->vg_vj)) return -1;
     }
-    HIPCHK(hipMalloc((void**)&h->vg_ib, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 0) * 8)));
-    HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_ib, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 256) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_ib64, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 64) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1024) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_jb256, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 256) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_best, 16));
-    ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 0, h->vg_ib);
-    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1, h->vg_jb);
+    ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 256, h->vg_ib);
+    ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 64, h->vg_ib64);
+    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1024, h->vg_jb);
+    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 256, h->vg_jb256);
     HIPCHK(hipGetLastError());
     h->vg_grid = ck_vario_grid(h->vg_ni, h->vg_nj);
+    h->vg_bgrid = ck_vario_bin_grid(h->vg_ni, h->vg_nj);
     HIPCHK(hipMalloc(&h->vg_part, h->vg_grid * sizeof(CkVarioExt)));
-    HIPCHK(hipMalloc((void**)&h->vg_psum, (size_t)h->vg_grid * CK_VG_MAXBINS * 8));
-    HIPCHK(hipMalloc((void**)&h->vg_pcnt, (size_t)h->vg_grid * CK_VG_MAXBINS * 8));
-    HIPCHK(hipMalloc((void**)&h->vg_out, (CK_VG_MAXBINS + 2 + 2 * CK_VG_MAXBINS) * 8));
-    HIPCHK(hipMalloc((void**)&h->vg_lut, CK_VG_LUT));
+    HIPCHK(hipMalloc((void**)&h->vg_psum, (size_t)h->vg_bgrid * CK_VG_MAXBINS * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_pcnt, (size_t)h->vg_bgrid * (CK_VG_MAXBINS + 1) * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_out, (2 * (CK_VG_MAXBINS + 2) + CK_VG_MAXBINS + CK_VG_MAXBINS + 1) * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_count, sizeof(unsigned)));
+    h->vg_list_cap = 1u << 20;
+    HIPCHK(hipMalloc((void**)&h->vg_list, (size_t)h->vg_list_cap * sizeof(CkVarioPair)));
+    for (int k = 0; k < 4; ++k) h->vg_stats[k] = 0;
     return 0;
 }
 
-// distance -> the monotone r the kernels compare (see ck_vario.hip)
-static double vario_r_of_dist(int metric, double d) {
-    if (metric == CK_METRIC_EUCLID) return d * d;
-    const long double a = (long double)d / (2.0L * CK_EARTH_RADIUS_KM);
-    if (a >= 1.57079632679489661923L) return 1.0 + 1e-12;   // beyond half the circumference: everything
-    const long double sn = sinl(a);
-    return (double)(sn * sn);
+// the list a kernel has just filled, on the host; *overflow = the kernel wanted more room than the list has --
+// the list is then re-allocated and the caller runs the kernel again
+static int vario_fetch_list(ck_handle* h, std::vector<CkVarioPair>& out, bool* overflow) {
+    unsigned cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->vg_count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *overflow = cnt > h->vg_list_cap;
+    if (*overflow) {
+        (void)hipFree(h->vg_list);
+        h->vg_list = nullptr;
+        const uint64_t want = (uint64_t)cnt + cnt / 4 + 1024;
+        if (want > 0xfffffff0ull) return fail("variogram: too many pairs on a bin edge for the host list");
+        h->vg_list_cap = (unsigned)want;
+        HIPCHK(hipMalloc((void**)&h->vg_list, (size_t)h->vg_list_cap * sizeof(CkVarioPair)));
+        return 0;
+    }
+    out.resize(cnt);
+    if (cnt) HIPCHK(hipMemcpy(out.data(), h->vg_list, (size_t)cnt * sizeof(CkVarioPair), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// fn(k) for k in [0, n) on a few host threads when n is large
+template <class F>
+static void host_parallel(int64_t n, F fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = n < 100000 ? 1 : (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    if (nt == 1) {
+        fn(0, 0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
 }
 
 extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64_t* n_positive) {
     CHKH(h);
     if (!h->vg_iu) return fail("ck_vario_begin has not been called");
-    const double rcap = vario_r_of_dist(h->metric, max_dist);
-    ck_launch_vario_extent(h->stream, h->vg_grid, h->metric, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj,
-                           rcap, h->vg_part, h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(h->metric, rcap), h->vg_best);
-    HIPCHK(hipGetLastError());
-    std::vector<CkVarioExt> part(h->vg_grid);
-    HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost,
-                          h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    CkVarioExt best = part[0];
-    for (int g = 1; g < h->vg_grid; ++g) {
-        if (part[g].rmin < best.rmin) {
-            best.rmin = part[g].rmin;
-            best.imin = part[g].imin;
-            best.jmin = part[g].jmin;
-        }
-        if (part[g].rmax > best.rmax) {
-            best.rmax = part[g].rmax;
-            best.imax = part[g].imax;
-            best.jmax = part[g].jmax;
-        }
-    }
-    *n_positive = (best.imin >= 0) ? 1 : 0;
+    if (!(max_dist >= 0.0)) return fail("max_dist must be >= 0");
     *lo = *hi = NAN;
-    // the two extreme pairs again, with the full-accuracy distance formula (on the device)
-    if (best.imin >= 0) {
-        double d = 0;
-        if (dense_common(h, 0, 0, 1, &h->vg_ci[2 * best.imin], 1, &h->vg_cj[2 * best.jmin], 1, &d)) return -1;
-        *lo = d;
+    *n_positive = 0;
+    const int metric = h->metric;
+    const double qcap0 = vario_q_of_dist(metric, max_dist);
+    double cap = qcap0 + vario_band(metric, qcap0);   // pairs up to here may still have d <= max_dist
+    bool have_lo = false, have_hi = false;
+    double best_lo = INFINITY, best_hi = -1.0;
+    // Round 0 normally settles both extremes.  Further rounds only when every pair within the band of the largest
+    // q <= cap turns out to lie beyond max_dist: the cap then moves below them.
+    for (int round = 0; round < 64 && !have_hi; ++round) {
+        ck_launch_vario_extent(h->stream, h->vg_grid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
+                               h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(cap), h->vg_best);
+        HIPCHK(hipGetLastError());
+        std::vector<CkVarioExt> part(h->vg_grid);
+        HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        CkVarioExt best = part[0];
+        for (int g = 1; g < h->vg_grid; ++g) {
+            if (part[g].rmin < best.rmin) {
+                best.rmin = part[g].rmin;
+                best.imin = part[g].imin;
+            }
+            if (part[g].rmax > best.rmax) {
+                best.rmax = part[g].rmax;
+                best.imax = part[g].imax;
+            }
+        }
+        if (best.imax < 0) break;   // no pair with q <= cap at all
+        // every pair whose q is within the band of an extreme is a candidate; the reference's formula decides
+        const double qtop_lo = best.rmax - 2.0 * vario_band(metric, best.rmax);
+        const double qbot_hi = (!have_lo && best.imin >= 0) ? best.rmin + 2.0 * vario_band(metric, best.rmin) : -1.0;
+        std::vector<CkVarioPair> cand;
+        for (int pass = 0; pass < 3; ++pass) {
+            HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
+            ck_launch_vario_collect(h->stream, h->vg_grid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, qtop_lo, cap,
+                                    qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib, h->vg_jb);
+            HIPCHK(hipGetLastError());
+            bool overflow = false;
+            if (vario_fetch_list(h, cand, &overflow)) return -1;
+            if (!overflow) break;
+            if (pass == 2) return fail("variogram: candidate list kept overflowing");
+        }
+        h->vg_stats[0] += (int64_t)cand.size();
+        if (round) h->vg_stats[3] += 1;
+        const int64_t nc = (int64_t)cand.size();
+        double tlo[8], thi[8];
+        for (int t = 0; t < 8; ++t) {
+            tlo[t] = INFINITY;
+            thi[t] = -1.0;
+        }
+        host_parallel(nc, [&](int t, int64_t a, int64_t b) {
+            double l = INFINITY, u = -1.0;
+            for (int64_t k = a; k < b; ++k) {
+                const double d = ref_distance(metric, &h->vg_ci[2 * (size_t)cand[k].i], &h->vg_cj[2 * (size_t)cand[k].j]);
+                if (d <= max_dist) {            // src/fields.py:212
+                    if (d > u) u = d;           // :395
+                    if (d > 0.0 && d < l) l = d;   // :394
+                }
+            }
+            tlo[t] = l;
+            thi[t] = u;
+        });
+        for (int t = 0; t < 8; ++t) {
+            if (thi[t] > best_hi) best_hi = thi[t];
+            if (tlo[t] < best_lo) best_lo = tlo[t];
+        }
+        have_hi = best_hi >= 0.0;
+        have_lo = best_lo < INFINITY;
+        if (!have_hi) {
+            if (!(qtop_lo > 0.0)) break;
+            cap = nextafter(qtop_lo, 0.0);   // everything from qtop_lo up is beyond max_dist
+        }
     }
-    if (best.imax >= 0) {
-        double d = 0;
-        if (dense_common(h, 0, 0, 1, &h->vg_ci[2 * best.imax], 1, &h->vg_cj[2 * best.jmax], 1, &d)) return -1;
-        *hi = d;
-    }
+    if (have_hi) *hi = best_hi;
+    if (have_lo) *lo = best_lo;
+    *n_positive = (have_lo && have_hi) ? 1 : 0;
     return 0;
 }
 
@@ -1600,44 +1732,101 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     for (int b = 0; b < nb; ++b)
         if (!(edges[b + 1] > edges[b])) return fail("bin edges must increase");
     if (edges[0] != 0.0) return fail("first bin edge must be 0 (src/fields.py:402)");
-    double thr[CK_VG_MAXBINS + 2];
-    for (int b = 0; b <= nb; ++b) thr[b] = vario_r_of_dist(h->metric, edges[b]);
-    thr[0] = 0.0;
-    const double cell = thr[nb] / CK_VG_LUT;
-    unsigned char lut[CK_VG_LUT];
-    {
-        int b = 0;
-        for (int c = 0; c < CK_VG_LUT; ++c) {
-            const double lo_end = c * cell;
-            while (b + 1 < nb && thr[b + 1] <= lo_end) ++b;
-            lut[c] = (unsigned char)b;
-            // at most two edges may fall inside one cell (the kernel fixes up twice)
-            int inside = 0;
-            for (int e = b + 1; e <= nb && thr[e] < lo_end + cell; ++e) ++inside;
-            if (inside > 2 && c + 1 < CK_VG_LUT) return fail("variogram bins too narrow near zero for the r-space lookup");
-        }
+    if (!(max_dist > 0.0)) return fail("max_dist must be positive");
+    const int metric = h->metric;
+    // Levels 1 .. E in ascending order: the inner edges below the cap, then the cap.  A pair's bin is the number of
+    // levels it passes (d > threshold: pd.cut's right-closed intervals, src/fields.py:214-216); a pair that passes
+    // level E is not retained (d > max_dist, :212, or beyond the last edge, where pd.cut yields no bin).
+    const double dcap = fmin(max_dist, edges[nb]);
+    double dthr[CK_VG_MAXBINS + 2], thi[CK_VG_MAXBINS + 2], tq[CK_VG_MAXBINS + 2];
+    int E = 0;
+    for (int e = 1; e < nb && edges[e] < dcap; ++e) dthr[++E] = edges[e];
+    dthr[++E] = dcap;
+    dthr[0] = thi[0] = tq[0] = 0.0;
+    double beta = 0.0;
+    for (int e = 1; e <= E; ++e) {
+        tq[e] = vario_q_of_dist(metric, dthr[e]);
+        const double bnd = vario_band(metric, tq[e]);
+        thi[e] = tq[e] + bnd;
+        if (!(tq[e] > 0.0)) return fail("variogram bin edge too close to zero");
+        beta = fmax(beta, bnd / tq[e]);
+        if (e > 1 && !(tq[e] - bnd > thi[e - 1])) return fail("variogram bin edges closer than the rounding band of the distances");
     }
-    const double rcap = vario_r_of_dist(h->metric, max_dist);
-    double* d_thr = h->vg_out;
-    double* d_sums = h->vg_out + CK_VG_MAXBINS + 2;
-    long long* d_cnt = (long long*)(h->vg_out + 2 * CK_VG_MAXBINS + 2);
-    HIPCHK(hipMemcpyAsync(d_thr, thr, (nb + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->vg_lut, lut, CK_VG_LUT, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    ck_launch_vario_bin(h->stream, h->vg_grid, h->metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv,
-                        h->vg_ni, h->vg_ju, h->vg_jv, h->vg_nj, rcap, nb, d_thr, h->vg_lut, 1.0 / cell, h->vg_psum,
-                        h->vg_pcnt, d_sums, d_cnt, h->rank, h->world, h->vg_ib, h->vg_jb,
-                        vario_cmax(h->metric, fmin(rcap, thr[nb])));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    long long cnt[CK_VG_MAXBINS];
-    HIPCHK(hipMemcpyAsync(sums, d_sums, nb * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(cnt, d_cnt, nb * 8, hipMemcpyDeviceToHost, h->stream));
+    const double gam = 1.0 + 2.5 * beta;
+    double* d_thi = h->vg_out;
+    double* d_dthr = h->vg_out + CK_VG_MAXBINS + 2;
+    double* d_sums = h->vg_out + 2 * (CK_VG_MAXBINS + 2);
+    long long* d_cnt = (long long*)(d_sums + CK_VG_MAXBINS);
+    HIPCHK(hipMemcpyAsync(d_thi, thi, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_dthr, dthr, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    std::vector<CkVarioPair> fix;
+    for (int pass = 0; pass < 3; ++pass) {
+        HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        ck_launch_vario_bin(h->stream, metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv, h->vg_ni, h->vg_ju,
+                            h->vg_jv, h->vg_nj, E, d_thi, d_dthr, gam, vario_cmax(thi[E]), h->vg_ib64, h->vg_jb, h->vg_jb256,
+                            h->vg_bgrid, h->vg_psum, h->vg_pcnt, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world,
+                            nb, d_sums, d_cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        bool overflow = false;
+        if (vario_fetch_list(h, fix, &overflow)) return -1;
+        if (!overflow) break;
+        if (pass == 2) return fail("variogram: edge-pair list kept overflowing");
+    }
+    long long cnt[CK_VG_MAXBINS + 1];
+    std::vector<double> sm(CK_VG_MAXBINS, 0.0);
+    HIPCHK(hipMemcpyAsync(sm.data(), d_sums, nb * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cnt, d_cnt, (CK_VG_MAXBINS + 1) * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int b = 0; b < nb; ++b) counts[b] = cnt[b];
+    for (int b = E; b < nb; ++b) {   // bins above the cap hold nothing
+        sm[(size_t)b] = 0.0;
+        cnt[b] = 0;
+    }
+    // Haversine: the pairs inside the band of a level were binned below it; the reference's formula on libm decides.
+    if (!fix.empty()) {
+        const int64_t nf = (int64_t)fix.size();
+        std::vector<double> dsum((size_t)8 * (CK_VG_MAXBINS + 1), 0.0);
+        std::vector<long long> dcnt((size_t)8 * (CK_VG_MAXBINS + 1), 0);
+        host_parallel(nf, [&](int t, int64_t a, int64_t b) {
+            double* ds = &dsum[(size_t)t * (CK_VG_MAXBINS + 1)];
+            long long* dc = &dcnt[(size_t)t * (CK_VG_MAXBINS + 1)];
+            for (int64_t k = a; k < b; ++k) {
+                const CkVarioPair& p = fix[(size_t)k];
+                if (p.lev < 1 || p.lev > E) continue;
+                const double d = ref_distance(metric, &h->vg_ci[2 * (size_t)p.i], &h->vg_cj[2 * (size_t)p.j]);
+                if (!(d > dthr[p.lev])) continue;   // stays in the bin below the level
+                const double va = h->vg_vi[(size_t)p.i], vb = h->vg_vj[(size_t)p.j];
+                const double cl = covariogram ? va * vb : 0.5 * ((va - vb) * (va - vb));   // src/fields.py:382-385
+                ds[p.lev - 1] -= cl;
+                dc[p.lev - 1] -= 1;
+                if (p.lev < E) {   // above the cap: not retained
+                    ds[p.lev] += cl;
+                    dc[p.lev] += 1;
+                }
+            }
+        });
+        for (int t = 0; t < 8; ++t)
+            for (int b = 0; b < nb && b <= E; ++b) {
+                sm[(size_t)b] += dsum[(size_t)t * (CK_VG_MAXBINS + 1) + b];
+                cnt[b] += dcnt[(size_t)t * (CK_VG_MAXBINS + 1) + b];
+            }
+    }
+    for (int b = 0; b < nb; ++b) {
+        sums[b] = sm[(size_t)b];
+        counts[b] = cnt[b];
+    }
+    h->vg_stats[1] = (int64_t)fix.size();
+    h->vg_stats[2] = cnt[CK_VG_MAXBINS];
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[9] = ms;
+    return 0;
+}
+
+extern "C" int ck_vario_stats(ck_handle* h, int64_t* out, int n) {
+    CHKH(h);
+    for (int k = 0; k < n && k < 4; ++k) out[k] = h->vg_stats[k];
     return 0;
 }
 

@@ -110,27 +110,35 @@ int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters
 
 // ---- empirical variogram (ck_vario.hip) ----------------------------------------------------
 #define CK_VG_MAXBINS 36
-#define CK_VG_LUT 8192
 struct CkVarioExt {
     double rmin, rmax;
     long long imin, jmin, imax, jmax;
 };
+// a pair the kernels leave to the host (indices in the order the device sees the points; lev: the level whose
+// band the pair lies in, 0 for the candidates of the extent pass)
+struct CkVarioPair {
+    int i, j, lev, pad;
+};
 void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int metric, double* u0, double* u1,
                           double* u2);
 int ck_vario_grid(int64_t ni, int64_t nj);
-// iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]
-void ck_launch_vario_extent(hipStream_t s, int grid, int metric, int same, const double* iu, int64_t ni,
-                            const double* ju, int64_t nj, double rcap, void* part, int rank, int world,
-                            const double* ib, const double* jb, double cmax, unsigned long long* best /* 2 words */);
-// tile culling (ck_vario.hip): bounding balls of the 256-point "i" blocks / 1024-point "j" chunks, 4 x nblk doubles;
-// cmax = largest chord |u_i - u_j| of a retained pair (with margin); ib == nullptr switches the culling off
-int64_t ck_vario_nblocks(int64_t n, int j_side);
-void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int j_side, double* out);
-void ck_launch_vario_bin(hipStream_t s, int grid, int metric, int same, int covariogram, const double* iu,
-                         const double* iv, int64_t ni, const double* ju, const double* jv, int64_t nj, double rcap,
-                         int nb, const double* thr, const unsigned char* lut, double inv_cell, double* part_sum,
-                         unsigned long long* part_cnt, double* sums, long long* counts, int rank, int world,
-                         const double* ib, const double* jb, double cmax);
+int ck_vario_bin_grid(int64_t ni, int64_t nj);
+// iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]; q = squared chord | squared distance
+void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
+                            int64_t nj, double qcap, void* part, int rank, int world, const double* ib, const double* jb,
+                            double cmax, unsigned long long* best /* 2 words */);
+void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
+                             int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
+                             unsigned cap, int rank, int world, const double* ib, const double* jb);
+// tile culling (ck_vario.hip): bounding balls of blocks of `blk` consecutive points, 4 x nblk doubles
+int64_t ck_vario_nblocks(int64_t n, int blk);
+void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, double* out);
+// levels 1 .. nlev (thi / dthr indexed by level); counts: CK_VG_MAXBINS + 1 words, the last = pairs visited
+void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, const double* iu, const double* iv,
+                         int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* thi,
+                         const double* dthr, double gam, double cmax, const double* ib64, const double* jb1024,
+                         const double* jb256, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
+                         unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts);
 
 // ---- local-neighbourhood cokriging (ck_local.hip) -------------------------------------------
 // pc: 3 x mpad prediction-site coordinates, sc: 3 x npad site coordinates (exact-formula form)

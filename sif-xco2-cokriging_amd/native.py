@@ -60,6 +60,8 @@ _PROTOS = {
     "ck_vario_extent": [c_void_p, c_double, _dp, _dp, POINTER(c_int64)],
     "ck_vario_bin": [c_void_p, c_double, _dp, c_int, c_int, _dp, POINTER(c_int64)],
     "ck_vario_end": [c_void_p],
+    "ck_vario_stats": [c_void_p, POINTER(c_int64), c_int],
+    "ck_ref_distance": [c_int, _dp, _dp, c_int64, _dp],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
     "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
@@ -138,6 +140,17 @@ def _f64(a, shape2=None):
 
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+def ref_distance(metric: int, A, B):
+    """The reference's distance arithmetic for n coordinate pairs on the host (libm), bit for bit
+    src/fields.py:332-342 -- what decides variogram ties (include/cokrige.h: ck_ref_distance)."""
+    A, B = _f64(A, 2), _f64(B, 2)
+    if A.shape != B.shape:
+        raise ValueError("A and B must have the same shape")
+    out = np.empty(A.shape[0])
+    _chk(lib().ck_ref_distance(int(metric), _p(A), _p(B), A.shape[0], _p(out)))
+    return out
 
 
 def device_count() -> int:
@@ -337,6 +350,11 @@ class Handle:
 
     def vario_end(self):
         _chk(lib().ck_vario_end(self._h))
+
+    def vario_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        _chk(lib().ck_vario_stats(self._h, out.ctypes.data_as(POINTER(c_int64)), 4))
+        return dict(zip(["extent_host_pairs", "bin_host_pairs", "bin_visited_pairs", "extent_extra_rounds"], out.tolist()))
 
     # -- diagnostics -----------------------------------------------------------------------------
     def debug_get_lower(self, n):

@@ -397,6 +397,72 @@ def fixture_vario():
     save("variogram", **out)
 
 
+def fixture_vario_lattice():
+    """Lattice data: many pairs sit at exactly the same distance, and max_dist / the bin edges coincide with
+    lattice distances, so the integer counts depend on the last bit of the distances and of the edges.
+    (a) Euclidean, a sim.CartesianGrid lattice with spacing 0.02 sampled semi-colocated; max_dist = 0.3 is a
+        lattice distance and n_bins = 8 gives bin width = 2 x spacing, so lattice distances fall ON the edges
+        (src/fields.py:212-216, 389-403);
+    (b) haversine, 0.05-degree lattice sites; max_dist = the reference's own distance between two sites 100 rows
+        apart on a meridian -- every such pair is retained or not by the last bit of sklearn's result."""
+    rng = np.random.default_rng(611)
+    grid = sim.CartesianGrid(xcount=51, ycount=51).coords.values          # spacing 0.02
+    pick = rng.choice(len(grid), size=900, replace=False)
+    e0, e1 = grid[pick[:600]], grid[pick[300:900]]                          # 300 shared sites
+    w0, w1 = rng.standard_normal(600), rng.standard_normal(600) * 0.7 + 0.2
+    mf = make_mf([e0, e1], [w0, w1], coords_all=[e0, e1], values_all=[w0, w1])
+    out = dict(e0=e0, e1=e1, w0=w0, w1=w1)
+    for tag, md, nb in (("a", 0.3, 8), ("b", 0.5, 13), ("c", 0.1, 5)):
+        out[f"euc_{tag}_cfg"] = np.array([md, nb], dtype=float)
+        for kind in ("Semivariogram", "Covariogram"):
+            cfg = fields.VarioConfig(md, nb, kind=kind, dist_units=None, fast_dist=False)
+            for (i, j) in ((0, 0), (0, 1), (1, 1)):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    df = mf.get_variogram(i, j, cfg)
+                key = f"euc_{tag}_{kind[:4].lower()}_{i}{j}"
+                out[key + "_centers"] = df["bin_center"].values.astype(float)
+                out[key + "_means"] = df["bin_mean"].values.astype(float)
+                out[key + "_counts"] = df["bin_count"].values.astype(np.int64)
+    # (b) haversine lattice: a dense patch so that many meridional pairs are exactly 100 rows apart
+    step = 0.05
+    lat = 30.0 + step / 2 + step * np.arange(0, 140)
+    lon = -100.0 + step / 2 + step * np.arange(0, 40)
+    la, lo = np.meshgrid(lat, lon, indexing="ij")
+    allp = np.column_stack([la.ravel(), lo.ravel()])
+    pick = rng.choice(len(allp), size=1500, replace=False)
+    c0, c1 = allp[pick[:1000]], allp[pick[500:1500]]
+    v0, v1 = rng.standard_normal(1000) + 0.1, rng.standard_normal(1000) * 1.3
+    mf = make_mf([c0, c1], [v0, v1], coords_all=[c0, c1], values_all=[v0, v1])
+    a, b = np.array([[lat[3], lon[7]]]), np.array([[lat[103], lon[7]]])
+    md_tie = float(fields.distance_matrix(a, b, fast_dist=True)[0, 0])     # ~555.97 km, a lattice distance
+    out.update(c0=c0, c1=c1, v0=v0, v1=v1)
+    for tag, md, nb in (("tie", md_tie, 20), ("plain", 400.0, 16)):
+        out[f"hav_{tag}_cfg"] = np.array([md, nb], dtype=float)
+        for kind in ("Semivariogram",):
+            cfg = fields.VarioConfig(md, nb, kind=kind)
+            for (i, j) in ((0, 0), (0, 1), (1, 1)):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    df = mf.get_variogram(i, j, cfg)
+                    cl = mf._variogram_cloud(i, j, cfg)
+                key = f"hav_{tag}_{i}{j}"
+                out[key + "_centers"] = df["bin_center"].values.astype(float)
+                out[key + "_means"] = df["bin_mean"].values.astype(float)
+                out[key + "_counts"] = df["bin_count"].values.astype(np.int64)
+                out[key + "_n_at_maxdist"] = np.array([int((cl.distance == md).sum()),
+                                                       int((np.abs(cl.distance - md) < 1e-9).sum())])
+    # a few thousand raw distances of both metrics for the bit-for-bit check of ck_ref_distance (CPU test)
+    ii, jj = rng.integers(0, 1000, 4000), rng.integers(0, 1000, 4000)
+    out["refd_hav_A"], out["refd_hav_B"] = c0[ii], c1[jj]
+    out["refd_hav"] = np.array([fields.distance_matrix(c0[x], c1[y], fast_dist=True)[0, 0] for x, y in zip(ii, jj)])
+    ii, jj = rng.integers(0, 600, 4000), rng.integers(0, 600, 4000)
+    out["refd_euc_A"], out["refd_euc_B"] = e0[ii], e1[jj]
+    out["refd_euc"] = np.array([fields.distance_matrix(e0[x], e1[y], units=None, fast_dist=False)[0, 0]
+                                for x, y in zip(ii, jj)])
+    save("variogram_lattice", **out)
+
+
 def fixture_sim():
     """sim.BivariateRandomField draw on a small grid (src/sim.py:33-54) -- generator parity."""
     mod = make_model(SET_KAT)

@@ -189,3 +189,30 @@ def test_composite_wls_and_fit_vs_reference():
     for (i, j) in ((0, 0), (0, 1), (1, 1)):
         sel = (g["theo_i"] == i) & (g["theo_j"] == j)
         np.testing.assert_allclose(orc.model_variogram(p, i, j, g["theo_distance"][sel]), g["theo_variogram"][sel], rtol=1e-12)
+
+
+def test_variogram_lattice_fixtures():
+    """Lattice data with max_dist / bin edges ON lattice distances: the counts hinge on the last bit of the
+    distances and edges (tests/golden/make_fixtures.py: fixture_vario_lattice); the oracle must be exact there."""
+    g = load_golden("variogram_lattice")
+    c, v = [g["e0"], g["e1"]], [g["w0"], g["w1"]]
+    for tag in ("a", "b", "c"):
+        md, nb = float(g[f"euc_{tag}_cfg"][0]), int(g[f"euc_{tag}_cfg"][1])
+        for kind in ("semi", "cova"):
+            for (i, j) in ((0, 0), (0, 1), (1, 1)):
+                centers, edges, means, counts = orc.variogram(c[i], v[i], c[j], v[j], i == j, EUC, md, nb,
+                                                              covariogram=(kind == "cova"))
+                key = f"euc_{tag}_{kind}_{i}{j}"
+                assert np.array_equal(counts, g[key + "_counts"]), key
+                np.testing.assert_allclose(centers, g[key + "_centers"], rtol=1e-15, atol=0)
+                ok = counts > 0
+                np.testing.assert_allclose(means[ok], g[key + "_means"][ok], rtol=1e-12, atol=1e-15)
+    c, v = [g["c0"], g["c1"]], [g["v0"], g["v1"]]
+    for tag in ("tie", "plain"):
+        md, nb = float(g[f"hav_{tag}_cfg"][0]), int(g[f"hav_{tag}_cfg"][1])
+        for (i, j) in ((0, 0), (0, 1), (1, 1)):
+            centers, edges, means, counts = orc.variogram(c[i], v[i], c[j], v[j], i == j, HAV, md, nb)
+            key = f"hav_{tag}_{i}{j}"
+            assert np.array_equal(counts, g[key + "_counts"]), key
+            np.testing.assert_array_equal(centers, g[key + "_centers"])
+    assert g["hav_tie_00_n_at_maxdist"][1] > g["hav_tie_00_n_at_maxdist"][0] > 0   # the tie case really has ties
