@@ -110,6 +110,14 @@ int ck_factor(ck_handle* h, int64_t* info);
  * Needs ck_factor; may be called repeatedly. */
 int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host);
 
+/* _verify_model (src/joint_prediction.py:60-66, 260-274): is the stacked matrix [[C_pp, c0^T], [c0, Sigma]] of the
+ * prediction sites of the LAST ck_predict positive definite?  Sigma is (ck_factor succeeded), so this is the
+ * Cholesky of the m x m Schur complement C_pp - V^T V on the solved right-hand sides that ck_predict left on the
+ * device (the reference factorises the (m + N) x (m + N) matrix).  info = 0: positive definite; > 0: LAPACK-style
+ * index of the failing leading minor among the prediction sites (library order) -- the reference then warns
+ * "Prediction joint covariance matrix is not positive definte".  Needs m (m + 512) / 2 more doubles of device memory. */
+int ck_verify_model(ck_handle* h, int64_t* info);
+
 /* Leave-one-out cross-validation of process i at all its data sites from ONE factorisation
  * (Predictor.cross_validation, src/joint_prediction.py:207-257, which re-solves per datum):
  * pred_q = z_q - (Sigma^-1 z)_q / (Sigma^-1)_qq, pred_err_q = sqrt(1 / (Sigma^-1)_qq); n_i values
@@ -207,7 +215,8 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
- * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local). */
+ * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local);
+ * [11] ck_verify_model (host wall clock, synchronised). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it

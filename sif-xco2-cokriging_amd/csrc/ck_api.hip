@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <utility>
 #include <thread>
@@ -105,6 +106,18 @@ struct ck_handle {
     int64_t p_cap = 0;
     double *d_pred = nullptr, *d_err = nullptr;
     double* d_pcoords = nullptr;
+    int aux_state = 0;   // 0: nothing usable | 1: right-hand sides assembled | 2: solved by ck_predict (rows = V^T, row m = y)
+    // Schur complement of the prediction sites (ck_verify_model), kept between calls with the same padded order
+    int64_t sch_M = 0;
+    std::vector<double*> sch_sig;
+    double** d_sch_ptr = nullptr;
+    int *d_sch_tile0 = nullptr, *d_sch_panel_of = nullptr;
+    int sch_tiles = 0;
+    double *sch_pc = nullptr, *sch_c = nullptr, *sch_u = nullptr;
+    CkMatern* d_sch_blk = nullptr;
+    CkTable* d_sch_tabs = nullptr;
+    double** d_sch_coefptr = nullptr;
+    long long* d_sch_info = nullptr;
     // empirical variogram state (ck_vario_*)
     std::vector<double> vg_ci, vg_cj, vg_vi, vg_vj;   // host copies of coordinates / residuals in the device's point order
                                                       // (the pairs the kernels leave to the host are decided on these)
@@ -211,12 +224,14 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
 }
 
 static void vario_free(ck_handle* h);
+static void schur_free(ck_handle* h);
 
 extern "C" int ck_destroy(ck_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     vario_free(h);
+    schur_free(h);
     for (void* p : h->owned) (void)hipFree(p);
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_info);
@@ -1075,6 +1090,7 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
     h->i_pred = i;
     h->m = m;
     h->mpad = mpad;
+    h->aux_state = pcoords ? 1 : 0;
     // large sets of prediction points are laid out along the Hilbert curve like the data sites
     // (site_order above); ck_aux_finish hands the results back in the caller's order
     std::vector<double> sorted;
@@ -1176,6 +1192,171 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     gemm_timed_collect(h, 7);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    h->aux_state = 2;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// _verify_model (src/joint_prediction.py:60-66, 260-274)
+// ---------------------------------------------------------------------------------------
+// The reference factorises the stacked (m + N) x (m + N) matrix [[C_pp, c0^T], [c0, Sigma]] and warns when
+// that fails.  Sigma is positive definite here (ck_factor succeeded), so the stacked matrix is positive definite
+// iff the Schur complement  S = C_pp - c0^T Sigma^-1 c0 = C_pp - V^T V  is, and V^T = (L^-1 c0)^T are exactly the
+// solved right-hand-side rows the last ck_predict left on the device: assemble C_pp (the auto-covariance of
+// process i at the prediction sites, nugget where h == 0, :94-102) in the packed panel format of Sigma, subtract
+// V^T V in one pass over the rows (ck_la.hip: k_schur_syrk_d), and run the same blocked Cholesky on it --
+// 2 N m^2 / 2 + m^3 / 3 flop instead of (m + N)^3 / 3.
+static void schur_free(ck_handle* h) {
+    for (double* p : h->sch_sig)
+        if (p) (void)hipFree(p);
+    h->sch_sig.clear();
+    void* ps[] = {h->d_sch_ptr, h->d_sch_tile0, h->d_sch_panel_of, h->sch_pc, h->sch_c, h->sch_u,
+                  h->d_sch_blk, h->d_sch_tabs, h->d_sch_coefptr, h->d_sch_info};
+    for (void* p : ps)
+        if (p) (void)hipFree(p);
+    h->d_sch_ptr = nullptr;
+    h->d_sch_tile0 = h->d_sch_panel_of = nullptr;
+    h->sch_pc = h->sch_c = h->sch_u = nullptr;
+    h->d_sch_blk = nullptr;
+    h->d_sch_tabs = nullptr;
+    h->d_sch_coefptr = nullptr;
+    h->d_sch_info = nullptr;
+    h->sch_M = 0;
+}
+
+// the factorisation drivers work on the handle's matrix: point them at the Schur complement for one sweep
+struct SchurSwap {
+    ck_handle* h;
+    std::vector<double*> sig;
+    double **d_sigptr, **d_panelptr;
+    int nK, time_gemm, world, rank;
+    int64_t Npad;
+    long long* d_info;
+    bool lookahead, assembled;
+    explicit SchurSwap(ck_handle* hh, int nJ, int64_t Mp) : h(hh) {
+        sig = h->sig;
+        d_sigptr = h->d_sigptr;
+        d_panelptr = h->d_panelptr;
+        nK = h->nK;
+        Npad = h->Npad;
+        d_info = h->d_info;
+        time_gemm = h->time_gemm;
+        lookahead = h->lookahead;
+        assembled = h->assembled;
+        world = h->world;
+        rank = h->rank;
+        h->sig = h->sch_sig;
+        h->d_sigptr = h->d_panelptr = h->d_sch_ptr;
+        h->nK = nJ;
+        h->Npad = Mp;
+        h->d_info = h->d_sch_info;
+        h->time_gemm = 0;
+        h->lookahead = false;
+        h->assembled = true;
+        h->world = 1;
+        h->rank = 0;
+    }
+    ~SchurSwap() {
+        h->sig = sig;
+        h->d_sigptr = d_sigptr;
+        h->d_panelptr = d_panelptr;
+        h->nK = nK;
+        h->Npad = Npad;
+        h->d_info = d_info;
+        h->time_gemm = time_gemm;
+        h->lookahead = lookahead;
+        h->assembled = assembled;
+        h->world = world;
+        h->rank = rank;
+    }
+};
+
+static int factor_sweep(ck_handle* h);
+
+extern "C" int ck_verify_model(ck_handle* h, int64_t* info) {
+    CHKH(h);
+    if (!info) return fail("null info");
+    if (h->world != 1) return fail("ck_verify_model is the single-process form");
+    if (h->aux_state != 2) return fail("ck_verify_model needs the solved right-hand sides of a preceding ck_predict");
+    const int64_t m = h->m, mpad = h->mpad;
+    *info = 0;
+    if (m <= 0) return 0;
+    const int64_t Mp = roundup(m, CK_NB);
+    const int nJ = (int)(Mp / CK_NB);
+    if (h->sch_M != Mp) {
+        schur_free(h);
+        h->sch_sig.assign((size_t)nJ, nullptr);
+        std::vector<int> tile0, panel_of;
+        int acc = 0;
+        for (int J = 0; J < nJ; ++J) {
+            const int64_t rows = Mp - (int64_t)J * CK_NB;
+            HIPCHK(hipMalloc((void**)&h->sch_sig[(size_t)J], (size_t)(rows * CK_NB + CK_PANEL_TAIL) * 8));
+            tile0.push_back(acc);
+            panel_of.push_back(J);
+            acc += (int)(rows / 64);
+        }
+        tile0.push_back(acc);
+        h->sch_tiles = acc;
+        HIPCHK(hipMalloc((void**)&h->d_sch_ptr, (size_t)nJ * sizeof(double*)));
+        HIPCHK(hipMemcpy(h->d_sch_ptr, h->sch_sig.data(), (size_t)nJ * sizeof(double*), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&h->d_sch_tile0, tile0.size() * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_sch_panel_of, (panel_of.size() + 1) * sizeof(int)));
+        HIPCHK(hipMemcpy(h->d_sch_tile0, tile0.data(), tile0.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_sch_panel_of, panel_of.data(), panel_of.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&h->sch_pc, (size_t)(2 * Mp) * 8));
+        HIPCHK(hipMalloc((void**)&h->sch_c, (size_t)(3 * Mp) * 8));
+        HIPCHK(hipMalloc((void**)&h->sch_u, (size_t)(3 * Mp) * 8));
+        HIPCHK(hipMalloc((void**)&h->d_sch_blk, 3 * sizeof(CkMatern)));
+        HIPCHK(hipMalloc((void**)&h->d_sch_tabs, 3 * sizeof(CkTable)));
+        HIPCHK(hipMalloc((void**)&h->d_sch_coefptr, 3 * sizeof(double*)));
+        HIPCHK(hipMalloc((void**)&h->d_sch_info, sizeof(long long)));
+        h->sch_M = Mp;
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    // the prediction sites as a one-process site set: every tile uses the auto-block (i, i), replicated into all
+    // three slots of the block / table arrays
+    const int bi = 2 * h->i_pred;
+    CkMatern hb[3] = {h->blk[bi], h->blk[bi], h->blk[bi]};
+    CkTable ht[3] = {h->tab[bi], h->tab[bi], h->tab[bi]};
+    double* hc[3] = {h->d_coef[bi], h->d_coef[bi], h->d_coef[bi]};
+    HIPCHK(hipMemcpyAsync(h->d_sch_blk, hb, sizeof(hb), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_sch_tabs, ht, sizeof(ht), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_sch_coefptr, hc, sizeof(hc), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->sch_pc, 0, (size_t)(2 * Mp) * 8, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sch_pc, h->d_pcoords, (size_t)(2 * m) * 8, hipMemcpyDeviceToDevice, h->stream));
+    ck_launch_prep_sites(h->stream, h->sch_pc, Mp, h->metric, h->sch_c, h->sch_c + Mp, h->sch_c + 2 * Mp, h->sch_u);
+    HIPCHK(hipStreamSynchronize(h->stream));   // hb / ht / hc are stack memory
+    const CkLayout L{m, Mp, Mp, Mp};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fast = tables_usable(h) && attempt == 0;
+        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        CkPanelMap pm{h->d_sch_tile0, h->d_sch_panel_of, h->d_sch_ptr, nJ, nullptr, 0};
+        ck_launch_assemble_sigma(h->stream, fast, h->d_sch_blk, h->d_sch_tabs, h->d_sch_coefptr, h->metric, h->sch_c,
+                                 h->sch_u, L, pm, h->sch_tiles, h->wl);
+        if (!fast) break;
+        ck_launch_assemble_fix(h->stream, false, h->d_sch_blk, h->metric, 0, nullptr, 0, h->sch_c, L, h->wl, h->d_sch_ptr,
+                               nullptr);
+        unsigned cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, h->wl.count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->fallback_total += cnt;
+        if (cnt <= h->wl.cap) break;
+    }
+    HIPCHK(hipGetLastError());
+    // row m of the right-hand sides is y = L^-1 z, not a prediction site (ck_aux_finish has consumed it)
+    HIPCHK(hipMemset2DAsync(h->aux + m * CK_NB, (size_t)mpad * CK_NB * 8, 0, (size_t)CK_NB * 8, (size_t)h->nK, h->stream));
+    ck_launch_schur_syrk(h->stream, h->d_sch_ptr, h->aux, mpad, h->nK, nJ, Mp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(h->d_sch_info, 0, sizeof(long long), h->stream));
+    long long v = 0;
+    {
+        SchurSwap swap(h, nJ, Mp);
+        if (factor_sweep(h)) return -1;   // records ev1 at its end
+        HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    *info = (int64_t)v;   // 1-based index among the prediction sites in the library's internal order, 0 = positive definite
+    h->t_ms[11] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }
 

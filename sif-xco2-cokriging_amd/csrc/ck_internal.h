@@ -84,6 +84,10 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
                           int Jstep, int nJ, int64_t Npad, int variant);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ, int variant, int64_t mrows);
+// S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur
+// complement (ck_verify_model); aux: np block columns of mpad x CK_NB solved right-hand-side rows
+void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,
+                          int64_t Mpad);
 void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
                            int nJ, int64_t Npad, int variant);
 // In-place Cholesky of the 64 x 64 diagonal block at A (ld); info_dev gets global_index0 + j + 1 of

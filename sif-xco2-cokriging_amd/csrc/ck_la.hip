@@ -769,6 +769,46 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(
     gemm_tile_d<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
 
+// Schur complement of the prediction sites, S = C_pp - V^T V (ck_verify_model): the solved right-hand-side rows
+// V^T (one row per prediction site, block column p of the data sites at aux + p * mpad * NB) are both operands;
+// block column J of S (rows J * NB .., packed like a Sigma panel) -= sum over ALL np data block columns in one
+// launch (K = np * 512: the C tile is read and written once).
+struct CkSrcSchur {
+    const double* aux;
+    long mpad;
+    int J;
+    long r0, c0;
+    __device__ __forceinline__ void get(int p, const ck_gchar*& A, const ck_gchar*& B) const {
+        const double* base = aux + (long)p * mpad * CK_NB + (long)J * CK_NB * CK_NB;
+        A = as_global(reinterpret_cast<const char*>(base + r0 * CK_NB));
+        B = as_global(reinterpret_cast<const char*>(base + c0 * CK_NB));
+    }
+};
+
+__global__ __launch_bounds__(512, 4) void k_schur_syrk_d(double* const* __restrict__ schur, const double* __restrict__ aux,
+                                                          long mpad, int np, long Mpad) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    const int J = (int)blockIdx.y;
+    const long M = Mpad - (long)J * CK_NB;
+    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if (r0 + 127 < c0) return;
+    if ((long)J * CK_NB + r0 + 128 > mpad) return;   // rows beyond the right-hand-side storage: padding, stays identity
+    const CkSrcSchur src{aux, mpad, J, r0, c0};
+    gemm_tile_d<8>(schur[J], CK_NB, src, np, r0, c0, lds);
+}
+
+void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,
+                          int64_t Mpad) {
+    if (nJ <= 0 || np <= 0) return;
+    const dim3 grid((unsigned)((Mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
+    k_schur_syrk_d<<<grid, dim3(512), 0, s>>>(schur_dev, aux, mpad, np, Mpad);
+}
+
 // block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
 template <int WAVES, int TN>
 __global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_syrk_group(

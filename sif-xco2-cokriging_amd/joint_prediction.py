@@ -16,10 +16,13 @@ factor is kept on the device, so further calls with new ``pcoords`` or another `
 one substitution sweep each.
 
 Deviations from the reference, all outside the arithmetic:
-  * the reference's ``_verify_model`` factorises the (m+N)x(m+N) stacked matrix only to
-    emit a warning (src/joint_prediction.py:60-66,260-274).  Here the same warning is
-    raised from the quantity that decides it in practice: a non-positive prediction
-    variance (see ``_warn_if_invalid``).
+  * the reference's ``_verify_model`` factorises the (m+N)x(m+N) stacked matrix to decide
+    whether to warn (src/joint_prediction.py:60-66,260-274).  Sigma is positive definite at
+    that point, so the stacked matrix is positive definite iff the m x m Schur complement
+    C_pp - c0^T Sigma^-1 c0 is: ``ck_verify_model`` factorises THAT, from the solved
+    right-hand sides the prediction left on the device (see ``_verify``).  Where the stacked
+    matrix is exactly singular (duplicate prediction sites; a site on a datum of the predicted
+    process) the reference's own outcome hangs on rounding; here those cases always warn.
   * without xarray installed the result is a pandas DataFrame indexed by the coordinate
     columns instead of an ``xarray.Dataset`` (same columns ``pred``, ``pred_err``).
 """
@@ -57,7 +60,12 @@ class Predictor:
         self.device = device
         self.timings = {}
         self.rhs_budget_bytes = 48 << 30   # device memory for the right-hand sides of one ck_predict call
+        # _verify_model: None = exact check (Cholesky of the m x m Schur complement on the device) for up to
+        # `verify_max_points` prediction sites and the variance test beyond; True / False force it on / off
+        self.verify_model = None
+        self.verify_max_points = 16384
         self._h = None
+        self._verdict = None
 
     # -- device state -------------------------------------------------------------------------
     def _new_handle(self, drop=None):
@@ -100,8 +108,10 @@ class Predictor:
             # resident factor in batches (one forward sweep each), sized by `rhs_budget_bytes`.
             n_pad = h.num_panels()[2]
             chunk = max(1024, int(self.rhs_budget_bytes // (8 * max(n_pad, 1))))
+            self._verdict = None
             if len(pc) <= chunk:
                 pred, err = h.predict(i, pc)
+                self._verdict = self._verify(h, i, pc, err)
             else:
                 parts = [h.predict(i, pc[a:a + chunk]) for a in range(0, len(pc), chunk)]
                 pred = np.concatenate([p for p, _ in parts])
@@ -116,11 +126,29 @@ class Predictor:
                 h.close()
         return pred, err
 
+    def _verify(self, h, i, pc, pred_err):
+        """True: the joint covariance of the data and these prediction sites is NOT positive definite
+        (the reference's _verify_model raises LinAlgError, src/joint_prediction.py:260-274); False: it is;
+        None: not checked exactly (switched off, or more than `verify_max_points` sites)."""
+        want = self.verify_model
+        if want is False or (want is None and len(pc) > self.verify_max_points):
+            return None
+        # exactly singular stacked matrices: two identical rows of pcoords, or a prediction site on a datum of
+        # process i (h == 0 puts the nugget into c0 as well, src/model.py:195-196) -- decided on the coordinates
+        rows = np.ascontiguousarray(pc).view([("a", np.float64), ("b", np.float64)]).ravel()
+        if len(np.unique(rows)) < len(rows):
+            return True
+        data = np.ascontiguousarray(np.asarray(self.mf.fields[i].coords_main, dtype=np.float64)[:, :2])
+        if np.isin(rows, data.view([("a", np.float64), ("b", np.float64)]).ravel()).any():
+            return True
+        return h.verify_model() != 0
+
     def _warn_if_invalid(self, pred_err):
-        # The stacked matrix of _verify_model is positive definite iff Sigma is (else we have
-        # already raised) and the prediction covariance Schur complement is; a prediction
-        # variance <= 0 (printed as pred_err == 0) is how that fails at data locations.
-        if np.any(pred_err <= 0.0):
+        bad = self._verdict
+        if bad is None:
+            # not checked exactly: the necessary condition the variances give (a non-positive Schur diagonal)
+            bad = bool(np.any(pred_err <= 0.0))
+        if bad:
             warnings.warn("Prediction joint covariance matrix is not positive definte; model"
                           " technically invalid.")
 

@@ -43,6 +43,7 @@ _PROTOS = {
     "ck_assemble_joint": [c_void_p],
     "ck_factor": [c_void_p, POINTER(c_int64)],
     "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
+    "ck_verify_model": [c_void_p, POINTER(c_int64)],
     "ck_loocv": [c_void_p, c_int, _dp, _dp],
     "ck_sample": [c_void_p, _dp, _dp, c_int64],
     "ck_num_panels": [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
@@ -264,6 +265,13 @@ class Handle:
         _chk(lib().ck_predict(self._h, int(i), _p(pc), m, _p(pred), _p(err)))
         return pred, err
 
+    def verify_model(self) -> int:
+        """0 if the joint covariance of data and the last predict()'s sites is positive definite, else the index
+        of the failing minor (src/joint_prediction.py:260-274; include/cokrige.h: ck_verify_model)."""
+        info = c_int64(0)
+        _chk(lib().ck_verify_model(self._h, byref(info)))
+        return info.value
+
     def loocv(self, i, n_i):
         pred, err = np.empty(n_i), np.empty(n_i)
         _chk(lib().ck_loocv(self._h, int(i), _p(pred), _p(err)))
@@ -405,7 +413,7 @@ class Handle:
         out = np.zeros(12)
         _chk(lib().ck_timings(self._h, _p(out), 12))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
-                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms"]
+                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):

@@ -463,6 +463,53 @@ def fixture_vario_lattice():
     save("variogram_lattice", **out)
 
 
+def fixture_verify():
+    """_verify_model (src/joint_prediction.py:60-66, 260-274): does the reference warn?
+    plain  -- valid model, generic sites: no warning;
+    indef  -- Sigma positive definite but the stacked matrix indefinite, with a POSITIVE diagonal of the
+              prediction covariance (an invalid cross-correlation only shows with the prediction sites clustered
+              around the other process's data): the reference warns, a test of the variances alone stays silent;
+    dup    -- two identical rows in pcoords (nugget > 0): stacked matrix exactly singular, the reference warns;
+    ondata -- a prediction site on a datum of the predicted process (nugget > 0): exactly singular too; the
+              reference's outcome then hangs on rounding (it warns for 4 of 6 seeds) -- seeds recorded."""
+    out = {}
+    SET_X = [1, 1, 1.5, 0.6, 1.5, 400, 400, 400, 0.02, 0.02, 0.7]   # rho too large for nu_12 < (nu_11 + nu_22) / 2
+    rng = np.random.default_rng(201)
+    c = [conus_points(rng, 30), conus_points(rng, 30)]
+    v = [rng.standard_normal(30), rng.standard_normal(30)]
+    pc = (c[1][:, None, :] + rng.normal(0, 0.3, (30, 6, 2))).reshape(-1, 2)
+    r = ref_joint(make_model(SET_X), make_mf(c, v), 0, pc, 0, verify=True)
+    P = joint_prediction.Predictor(make_model(SET_X), make_mf(c, v))
+    P.i = 0
+    sch = P._pred_cov(pc) - r["W"] @ r["c0"]
+    assert r["warned"] and np.diag(sch).min() > 0
+    out.update(indef_params=np.array(SET_X, float), indef_c0=c[0], indef_c1=c[1], indef_v0=v[0], indef_v1=v[1],
+               indef_pc=pc, indef_warned=np.array(r["warned"]), indef_pred=r["pred"], indef_pred_err=r["pred_err"],
+               indef_min_schur_diag=np.array(np.diag(sch).min()), indef_min_schur_eig=np.array(np.linalg.eigvalsh(sch).min()))
+    rng = np.random.default_rng(100)
+    c = [conus_points(rng, 120), conus_points(rng, 100)]
+    v = [rng.standard_normal(120), rng.standard_normal(100)]
+    pc = conus_points(rng, 60)
+    mod, mf = make_model(SET_A), make_mf(c, v)
+    out.update(A_params=np.array(SET_A, float), A_c0=c[0], A_c1=c[1], A_v0=v[0], A_v1=v[1])
+    r = ref_joint(mod, mf, 0, pc, 0, verify=True)
+    out.update(plain_pc=pc, plain_warned=np.array(r["warned"]), plain_pred=r["pred"], plain_pred_err=r["pred_err"])
+    pc2 = pc.copy()
+    pc2[17] = pc2[3]
+    r = ref_joint(mod, mf, 0, pc2, 0, verify=True)
+    out.update(dup_pc=pc2, dup_warned=np.array(r["warned"]), dup_pred=r["pred"], dup_pred_err=r["pred_err"])
+    pc3 = pc.copy()
+    pc3[5] = c[0][7]
+    r = ref_joint(mod, mf, 0, pc3, 0, verify=True)
+    out.update(ondata_pc=pc3, ondata_warned=np.array(r["warned"]), ondata_pred=r["pred"], ondata_pred_err=r["pred_err"])
+    pc4 = pc.copy()
+    pc4[5] = c[1][7]          # on a datum of the OTHER process: not singular
+    r = ref_joint(mod, mf, 0, pc4, 0, verify=True)
+    out.update(onother_pc=pc4, onother_warned=np.array(r["warned"]), onother_pred=r["pred"], onother_pred_err=r["pred_err"])
+    print("verify fixture warned flags:", {k: bool(out[k]) for k in out if k.endswith("_warned")})
+    save("verify_model", **out)
+
+
 def fixture_sim():
     """sim.BivariateRandomField draw on a small grid (src/sim.py:33-54) -- generator parity."""
     mod = make_model(SET_KAT)

@@ -216,3 +216,21 @@ def test_variogram_lattice_fixtures():
             assert np.array_equal(counts, g[key + "_counts"]), key
             np.testing.assert_array_equal(centers, g[key + "_centers"])
     assert g["hav_tie_00_n_at_maxdist"][1] > g["hav_tie_00_n_at_maxdist"][0] > 0   # the tie case really has ties
+
+
+def test_verify_model_fixture():
+    """The oracle's restatement of _verify_model (stacked (m+N)^2 factorisation) warns exactly where the reference did
+    (tests/golden/make_fixtures.py: fixture_verify); the indefinite case has a POSITIVE prediction-variance diagonal."""
+    import warnings
+    g = load_golden("verify_model")
+    assert g["indef_min_schur_diag"] > 0 > g["indef_min_schur_eig"]
+    cases = [("indef", "indef", 0)] + [(t, "A", 0) for t in ("plain", "dup", "ondata", "onother")]
+    for tag, dset, i in cases:
+        p = orc.Params.from_flat(g[f"{dset}_params"])
+        c, v = [g[f"{dset}_c0"], g[f"{dset}_c1"]], [g[f"{dset}_v0"], g[f"{dset}_v1"]]
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pred, err = orc.joint_predict(p, c, v, g[f"{tag}_pc"], i, HAV, verify=True)
+        warned = any("not positive definte" in str(x.message) for x in w)
+        assert warned == bool(g[f"{tag}_warned"]), tag
+        np.testing.assert_allclose(pred, g[f"{tag}_pred"], rtol=1e-9, atol=1e-12)
