@@ -53,35 +53,102 @@ def aux_update_flops(N, m, NB=512):
     return tot
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (numpy/scipy restatement of the reference path) timed on this host's cores on a
-    bounded sample of the same workload: same lattice, same model, same 0.5-degree grid
-    resolution, n = 3 000 per process (N = 6 000) and the first 4 000 grid points (the full
-    n = 20 000 problem is ~50x the assembly and ~300x the factorisation work of the sample)."""
+def cpu_baseline(N_full, m_full):
+    """The reference path on this host's cores, stage by stage, on a bounded sample of the same workload
+    (SURVEY.md section 8d / BASELINE.md section 3): same lattice, same model, same 0.5-degree grid resolution,
+    n = 3 000 per process (N = 6 000) and the first 4 000 grid points.  The oracle's functions are the
+    reference's lines restated (numpy, scipy.special.kv, sklearn haversine, LAPACK through scipy), timed in the
+    order Predictor.__call__ runs them (src/joint_prediction.py:49-78).  `value` counts the stages that produce
+    the output (Sigma, c0, cho_factor, cho_solve, the reductions as the reference does them: a full m x N x m
+    product for a diagonal); the two diagnostic stages (m x m _pred_cov, _verify_model) are listed separately.
+    `extrapolation` scales each stage by its operation count to the full size -- labelled as such."""
     import numpy as np
+    from scipy.linalg import cho_factor, cho_solve
     from oracle import cokrige_oracle as orc
     from sif_xco2_cokriging_amd import synth
     n, m = 3000, 4000
+    N = 2 * n
     pb = synth.conus_problem(n, seed=20003)
     p = orc.Params.from_flat(pb["params"])
-    t0 = time.perf_counter()
-    orc.joint_predict(p, pb["coords"], pb["values"], pb["pcoords"][:m], 0, pb["metric"])
-    dt = time.perf_counter() - t0
+    pc, metric = pb["pcoords"][:m], pb["metric"]
+    st = {}
+
+    def timed(key, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        st[key] = time.perf_counter() - t0
+        return out
+
+    S = timed("joint_cov_s", lambda: orc.joint_cov(p, pb["coords"], metric))                      # :124-153
+    c0 = timed("pred_cross_cov_s", lambda: orc.pred_cross_cov(p, pb["coords"], pc, 0, metric))    # :104-122
+    z = np.hstack(pb["values"])
+    cf = timed("cho_factor_s", lambda: cho_factor(S.copy(), lower=True, overwrite_a=True, check_finite=False))   # :69
+    W = timed("cho_solve_s", lambda: cho_solve(cf, c0.copy(), overwrite_b=True, check_finite=False).T)          # :68-73
+    C_pp = timed("pred_cov_diagnostic_s", lambda: orc.pred_cov(p, pc, 0, metric))                 # :94-102 (m x m)
+
+    def reduce_():
+        var = np.diagonal(C_pp - np.matmul(W, c0))                                                # :74
+        with np.errstate(invalid="ignore"):
+            return np.matmul(W, z), np.nan_to_num(np.sqrt(var))                                   # :77-78
+    timed("reductions_s", reduce_)
+
+    def verify_():
+        try:
+            cho_factor(np.vstack([np.hstack([C_pp, c0.T]), np.hstack([c0, S])]), overwrite_a=True)   # :260-274
+        except Exception:
+            pass
+    timed("verify_model_diagnostic_s", verify_)
+    core = ("joint_cov_s", "pred_cross_cov_s", "cho_factor_s", "cho_solve_s", "reductions_s")
+    dt = sum(st[k] for k in core)
+    rN, rm = N_full / N, m_full / m
+    scale = {"joint_cov_s": rN ** 2, "pred_cross_cov_s": rN * rm, "cho_factor_s": rN ** 3, "cho_solve_s": rN ** 2 * rm,
+             "reductions_s": rN * rm ** 2, "pred_cov_diagnostic_s": rm ** 2, "verify_model_diagnostic_s": (
+                 (N_full + m_full) / (N + m)) ** 3}
+    ext = {k: st[k] * scale[k] for k in st}
+    ext_core = sum(ext[k] for k in core)
     return {"value": m / dt, "unit": "grid-points/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle joint_predict, n_obs={n}/process (N={2*n}), m={m} grid points, {dt:.1f} s wall; "
-                      f"numpy/scipy with BLAS threads = all {os.cpu_count()} host cores"}
+            "sample": f"oracle stages of joint Predictor.__call__, n_obs={n}/process (N={N}), m={m} grid points, "
+                      f"{dt:.1f} s for the output-producing stages (+ {st['pred_cov_diagnostic_s'] + st['verify_model_diagnostic_s']:.1f} s "
+                      f"diagnostics); numpy/scipy, BLAS threads = all {os.cpu_count()} host cores, covariance assembly single-threaded as in the reference",
+            "stages": {k: round(v, 4) for k, v in st.items()},
+            "extrapolation": {"label": "EXTRAPOLATED from the sample by operation count, not measured",
+                              "to": f"N={N_full}, m={m_full}", "stages_s": {k: round(v, 2) for k, v in ext.items()},
+                              "output_stages_s": round(ext_core, 1), "grid_points_per_s": m_full / ext_core,
+                              "with_diagnostics_grid_points_per_s": m_full / sum(ext.values())}}
 
 
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/):
-    WRITE_SIZE + FETCH_SIZE in separate rocprofv3 --pmc runs, KB -> bytes; null if absent."""
-    p = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("k_syrk_group_bytes_per_launch")
-        except Exception:
-            return None
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this round
+    (profiles/r02_traffic.json; scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
+    runs of this very command, KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
+    streams).  A committed measurement of the same workload, not a live counter: null if absent."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)).get("k_syrk_group_bytes_per_launch")
+            except Exception:
+                return None
     return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process and
+    pass its exit code on.  This process never touches the GPU (device_count() does not initialise it)."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("CK_DIST_BACKEND", "nccl")
+    nd = torch.cuda.device_count()
+    if backend == "nccl" and nd < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {nd} GPU(s) visible (RCCL needs one per rank; "
+                         f"CK_DIST_BACKEND=gloo rehearses the multi-rank path on fewer)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -97,10 +164,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
@@ -111,6 +182,8 @@ def main():
     backend = os.environ.get("CK_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible: RCCL needs one GPU per rank")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -164,9 +237,12 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     tim = []
+    rank_tim = []
     for _ in range(args.steps):
         pred, err = step()
         tim.append(h.timings())
+        if world > 1:
+            rank_tim.append(dict(runner.timings))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -176,6 +252,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    per_rank = None
+    if dist is not None:
+        # every rank's own breakdown of a step (HIP events on its stream, mean over the timed steps)
+        keys = ("panel_ms", "update_ms", "bcast_wait_ms", "assemble_ms", "finish_ms")
+        mine = torch.tensor([float(np.mean([t.get(k, 0.0) for t in rank_tim])) for k in keys], dtype=torch.float64, device="cuda")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(zip(keys, [round(float(x), 3) for x in t.cpu().tolist()])) for t in allr]
 
     if rank == 0:
         out = {
@@ -199,6 +283,14 @@ def main():
                                     f"Matern set {args.params}"),
                        "n_obs": n, "N": N, "m": m, "params": pv, "partition": f"block-column-cyclic x{world}"},
         }
+        if per_rank is not None:
+            nK = -(-N // 512)
+            out["per_rank"] = per_rank
+            out["comm"] = {"collective": "panel broadcast (RCCL over xGMI), one per 512-column panel, look-ahead depth 1",
+                           "panels": nK, "bytes_received_per_rank_per_step": int(sum((nK * 512 - K * 512) * 512 * 8 + 8 * 64 * 64 * 8
+                                                                                     for K in range(nK) if K % world != 0)),
+                           "note": "bcast_wait_ms = time the rank's stream waited for a panel after its own updates were done "
+                                   "(exposed communication); panel_ms / update_ms = panel steps / trailing + right-hand-side updates"}
         if world > 1 and tim[-1]["syrk_launches"] > 0:
             # rank 0's share of the trailing updates: block column J (owned if J % world == 0) receives J panels
             nK = -(-N // 512)
@@ -242,8 +334,24 @@ def main():
                 # factor reused: grid-points/s of one more ck_predict on the resident L (K2 + K4 + reduce)
                 "amortised_grid_points_per_s": m / ((tl["assemble_aux_ms"] + tl["solve_ms"] + tl["reduce_ms"]) / 1e3),
             }
+            if args.config == 2 and n == 20000:
+                # PCIe-inclusive figure (never `value`): host arrays to host results in one timed region -- new handle, model,
+                # upload of the sites (with the Hilbert sort on the host), tables, assembly, factorisation, sweep, results back
+                t0 = time.perf_counter()
+                h2 = native.Handle(local_rank)
+                h2.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+                h2.set_metric(pb["metric"])
+                for k in range(2):
+                    h2.set_data(k, pb["coords"][k], pb["values"][k])
+                h2.assemble_joint()
+                h2.factor()
+                h2.predict(0, pb["pcoords"])
+                dtc = time.perf_counter() - t0
+                h2.close()
+                out["pcie_inclusive"] = {"ms": dtc * 1e3, "grid_points_per_s": m / dtc,
+                                         "what": "one cold pass, host arrays -> host results, new handle (not the headline value)"}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(N, m)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

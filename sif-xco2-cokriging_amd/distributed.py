@@ -35,13 +35,39 @@ from . import native
 _BIG = np.iinfo(np.int64).max
 
 
+class _Marks:
+    """Time stamps on the rank's stream (HIP events through torch) or, for the CPU stand-in of the tests, on the
+    host clock.  ms(a, b) is valid after the stream has been synchronised."""
+
+    def __init__(self, device):
+        self.cuda = device is not None and str(device).startswith("cuda")
+        self.device = device
+
+    def mark(self):
+        if self.cuda:
+            import torch
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            return e
+        import time
+        return time.perf_counter()
+
+    def ms(self, a, b):
+        return float(a.elapsed_time(b)) if self.cuda else (b - a) * 1e3
+
+
 class DistributedJoint:
     def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
         self.lookahead = bool(lookahead)
         self.arena = None
+        # this rank's breakdown of the last predict(): panel_ms (panel steps it owned, incl. the look-ahead column
+        # update in front of them), update_ms (trailing + right-hand-side updates, collective enqueue), bcast_wait_ms
+        # (its stream waiting for a panel after its own updates: exposed communication), assemble_ms, finish_ms
         self.timings = {}
+        self._marks = _Marks(device)
+        self._steps = []
 
     # -- setup ------------------------------------------------------------------------------------
     def shard(self, m_total: int):
@@ -81,21 +107,30 @@ class DistributedJoint:
         kernel holds its few CUs before they fill the chip; it reads panel K + 1 and writes the
         receive buffer (K + 1) & 1, the update reads panel K (buffer K & 1) and writes columns
         beyond K + 1 -- disjoint."""
-        h, dist = self.h, self.dist
+        h, dist, mk = self.h, self.dist, self._marks.mark
+        t0 = mk()
         if self.rank == 0:
             h.panel_factor(0)
+        t1 = mk()
         dist.broadcast(self._panel_tensor(0), src=0, group=self.group)
+        self._steps.append((t0, t1, t1, mk()))
         for K in range(nK):
             nxt, work = K + 1, None
+            t0 = mk()
             if nxt < nK:
                 if nxt % self.world == self.rank:
                     h.panel_apply_sigma(K, nxt, nxt)
                     h.panel_factor(nxt)
+                t1 = mk()
                 work = dist.broadcast(self._panel_tensor(nxt), src=nxt % self.world, group=self.group, async_op=True)
+            else:
+                t1 = t0
             h.panel_apply_sigma(K, nxt + 1, nK - 1)
             h.panel_apply(K, native.APPLY_AUX)
+            t2 = mk()
             if work is not None:
                 work.wait()
+            self._steps.append((t0, t1, t2, mk()))
 
     # -- one pass of the hot path ---------------------------------------------------------------------
     def predict(self, i: int, pcoords):
@@ -107,21 +142,44 @@ class DistributedJoint:
         pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
         m = pc.shape[0]
         lo, hi, chunk = self.shard(m)
+        mk = self._marks.mark
+        self._steps = []
+        ta = mk()
         h.assemble_joint()
         h.aux_begin(i, pc[lo:hi])
+        tb = mk()
         nK, _, _ = h.num_panels()
         if self.world > 1 and self.lookahead:
             self._sweep_lookahead(nK)
         else:
             for K in range(nK):
                 owner = K % self.world
+                t0 = mk()
                 if owner == self.rank:
                     h.panel_factor(K)
+                t1 = mk()
                 if self.world > 1:
                     dist.broadcast(self._panel_tensor(K), src=owner, group=self.group)
+                t2 = mk()
                 h.panel_apply(K, native.APPLY_SIGMA | native.APPLY_AUX)
+                t3 = mk()
+                self._steps.append((t0, t1, t3, t3, t1, t2))   # plain schedule: the wait sits between t1 and t2
+        tc = mk()
         pred_l, err_l = h.aux_finish()
         info = h.factor_info()
+        td = mk()
+        ms = self._marks.ms
+        tm = {"assemble_ms": ms(ta, tb), "finish_ms": ms(tc, td), "panel_ms": 0.0, "update_ms": 0.0, "bcast_wait_ms": 0.0}
+        for st in self._steps:
+            if len(st) == 4:
+                tm["panel_ms"] += ms(st[0], st[1])
+                tm["update_ms"] += ms(st[1], st[2])
+                tm["bcast_wait_ms"] += ms(st[2], st[3])
+            else:
+                tm["panel_ms"] += ms(st[0], st[1])
+                tm["bcast_wait_ms"] += ms(st[4], st[5])
+                tm["update_ms"] += ms(st[5], st[2])
+        self.timings = tm
         if self.world == 1:
             pred, err = pred_l, err_l
         else:

@@ -36,7 +36,7 @@ class _GlooViaHost:
             o.copy_(c)
 
 
-def _worker(rank, world, port, q, via_host):
+def _worker(rank, world, port, q, via_host, big=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -48,11 +48,13 @@ def _worker(rank, world, port, q, via_host):
         g = load_golden("joint_solve")
         # enlarge the problem beyond one 512-panel per rank: 3 panels
         rng = np.random.default_rng(11)
-        lat = rng.uniform(25, 50, 1300)
-        lon = rng.uniform(-120, -70, 1300)
+        npts = 4300 if big else 1300         # big: N = 4 600 -> 9 panels, look-ahead over several owners' turns
+        lat = rng.uniform(25, 50, npts)
+        lon = rng.uniform(-120, -70, npts)
         pts = np.column_stack([lat, lon])
-        coords = [pts[:700], pts[500:1300]]
-        values = [rng.standard_normal(700), rng.standard_normal(800)]
+        n0 = 2300 if big else 700
+        coords = [pts[:n0], pts[n0 - 200:npts]]
+        values = [rng.standard_normal(len(coords[0])), rng.standard_normal(len(coords[1]))]
         pv = g["params_A"]
         h = native.Handle(0)
         h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
@@ -64,13 +66,14 @@ def _worker(rank, world, port, q, via_host):
         dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
         r = DistributedJoint(h, rank, world, dist_module=dm, device=dev).prepare(len(g["pcoords_A"]))
         pred, err = r.predict(0, g["pcoords_A"])
+        assert r.timings["update_ms"] > 0 and r.timings["bcast_wait_ms"] >= 0
         q.put((rank, pred, err, coords, values))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("via_host", [True, False])
-def test_two_ranks_one_gpu_matches_oracle(via_host):
+@pytest.mark.parametrize("via_host,big", [(True, False), (False, False), (False, True)])
+def test_two_ranks_one_gpu_matches_oracle(via_host, big):
     import torch.multiprocessing as mp
     from oracle import cokrige_oracle as orc
     s = socket.socket()
@@ -79,7 +82,7 @@ def test_two_ranks_one_gpu_matches_oracle(via_host):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, via_host)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, via_host, big)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _queue
