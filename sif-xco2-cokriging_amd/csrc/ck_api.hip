@@ -27,6 +27,8 @@
 #include "ck_internal.h"
 #include "ck_model.h"
 
+static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
 static thread_local std::string g_err;
 static int fail(const std::string& msg) {
     g_err = msg;
@@ -42,6 +44,22 @@ static int fail(const std::string& msg) {
 #define CHKH(h)                       \
     if (!(h)) return fail("null handle"); \
     HIPCHK(hipSetDevice((h)->device))
+
+// device temporaries of one call: released on every return path
+struct DevTemps {
+    std::vector<void*> p;
+    ~DevTemps() {
+        for (void* x : p)
+            if (x) (void)hipFree(x);
+    }
+    template <class T>
+    hipError_t get(T** out, size_t bytes) {
+        *out = nullptr;
+        const hipError_t e = hipMalloc((void**)out, bytes ? bytes : 8);
+        if (e == hipSuccess) p.push_back((void*)*out);
+        return e;
+    }
+};
 
 struct EvPair {
     hipEvent_t a, b;
@@ -106,6 +124,8 @@ struct ck_handle {
     int64_t p_cap = 0;
     double *d_pred = nullptr, *d_err = nullptr;
     double* d_pcoords = nullptr;
+    char* mv_buf = nullptr;   // ck_model_variogram's device rows (i, j, lag, out), kept between the cost evaluations of a fit
+    int64_t mv_cap = 0;
     int aux_state = 0;   // 0: nothing usable | 1: right-hand sides assembled | 2: solved by ck_predict (rows = V^T, row m = y)
     // Schur complement of the prediction sites (ck_verify_model), kept between calls with the same padded order
     int64_t sch_M = 0;
@@ -141,7 +161,7 @@ struct ck_handle {
     int time_gemm = 0;   // 1: bracket every trailing-update launch with events | 2: the Sigma updates only (step-wise form)
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     // look-ahead: the panel step of column K+1 runs on a second (high-priority) stream under the
     // trailing update of panel K
     hipStream_t side = nullptr;
@@ -150,7 +170,6 @@ struct ck_handle {
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
     int panel_group = 0;   // 0 = automatic: 3 for 40 or more panels, else 1 (measured: the one-column in-group
                            // launches cost more than the saved C traffic on small matrices)
-    int gemm_variant = CK_GEMM_DEFAULT;   // option "gemm_variant"
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     int local_tile_min = 64;     // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
@@ -211,6 +230,8 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
     h->stream = h->own_stream;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipEventCreate(&h->ev2));
+    HIPCHK(hipEventCreate(&h->ev3));
     {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -250,6 +271,9 @@ extern "C" int ck_destroy(ck_handle* h) {
     }
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
+    (void)hipEventDestroy(h->ev2);
+    (void)hipEventDestroy(h->ev3);
+    if (h->mv_buf) (void)hipFree(h->mv_buf);
     for (auto e : h->ev_col) (void)hipEventDestroy(e);
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -324,7 +348,8 @@ extern "C" int ck_set_data(ck_handle* h, int k, const double* coords, const doub
     CHKH(h);
     if (k < 0 || k > 1) return fail("process index must be 0 or 1");
     if (n_k < 0 || (n_k > 0 && (!coords || !values))) return fail("bad data arrays");
-    if (h->layout_ready) return fail("data already laid out on the device; create a new handle to change it");
+    // also after ck_set_metric has invalidated the layout: the site arrays and panels keep their first sizes
+    if (h->layout_ready || h->s0) return fail("data already laid out on the device; create a new handle to change it");
     h->h_coords[k].assign(coords, coords + 2 * n_k);
     h->h_values[k].assign(values, values + n_k);
     h->n[k] = n_k;
@@ -332,7 +357,6 @@ extern "C" int ck_set_data(ck_handle* h, int k, const double* coords, const doub
     return 0;
 }
 
-static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------
 // tabulated covariance: build C(q) = amp * rho tables for every Matern block of the model
@@ -354,11 +378,12 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
         HIPCHK(hipMalloc((void**)&h->d_coefptr, 3 * sizeof(double*)));
         for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void**)&h->d_coef[b], (size_t)ND * CK_TAB_STRIDE * 8));
     }
+    DevTemps tmp;
     unsigned long long* d_err = nullptr;
     double *d_q = nullptr, *d_f = nullptr;
-    HIPCHK(hipMalloc((void**)&d_err, 8));
-    HIPCHK(hipMalloc((void**)&d_q, (size_t)ND * CK_TAB_STRIDE * 8));
-    HIPCHK(hipMalloc((void**)&d_f, (size_t)ND * CK_TAB_STRIDE * 8));
+    HIPCHK(tmp.get(&d_err, (size_t)(8)));
+    HIPCHK(tmp.get(&d_q, (size_t)((size_t)ND * CK_TAB_STRIDE * 8)));
+    HIPCHK(tmp.get(&d_f, (size_t)((size_t)ND * CK_TAB_STRIDE * 8)));
     std::vector<double> hq(ND * CK_TAB_STRIDE), hf(ND * CK_TAB_STRIDE), hcoef(ND * CK_TAB_STRIDE);
     for (int b = 0; b < 3; ++b) {
         CkTable& T = h->tab[b];
@@ -398,9 +423,6 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     HIPCHK(hipMemcpyAsync(h->d_tabs, h->tab, 3 * sizeof(CkTable), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_coefptr, h->d_coef, 3 * sizeof(double*), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_err);
-    (void)hipFree(d_q);
-    (void)hipFree(d_f);
     h->tables_built = true;
     return 0;
 }
@@ -524,8 +546,9 @@ static int ensure_layout(ck_handle* h) {
             hz[off + j] = h->h_values[k][e];
         }
     }
+    DevTemps tmp;
     double* d_tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tmp, 2 * Np * 8));
+    HIPCHK(tmp.get(&d_tmp, (size_t)(2 * Np * 8)));
     HIPCHK(hipMemcpyAsync(d_tmp, hc.data(), 2 * Np * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->z, hz.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, d_tmp, Np, h->metric, h->s0, h->s1, h->s2, h->su);
@@ -535,7 +558,6 @@ static int ensure_layout(ck_handle* h) {
     }
     ck_launch_local_chunk_bounds(h->stream, h->su, CkLayout{h->n[0], h->n0p, h->nend, h->Npad}, h->d_chunkb);
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipFree(d_tmp));
     // squared bounding-box diagonal of the data sites (Euclidean table range)
     const double qbox = (bhi[0] - blo[0]) * (bhi[0] - blo[0]) + (bhi[1] - blo[1]) * (bhi[1] - blo[1]);
     if (build_tables(h, qbox)) return -1;
@@ -590,12 +612,13 @@ static int blk_index(ck_handle* h, int i, int j, int* idx) {
 static int dense_common(ck_handle* h, int bidx, int add_nugget, int mode, const double* A, int64_t a, const double* B,
                         int64_t b, double* out) {
     if (a <= 0 || b <= 0) return 0;
+    DevTemps tmp;
     double *dA = nullptr, *dB = nullptr, *dO = nullptr, *ta = nullptr, *tb = nullptr;
-    HIPCHK(hipMalloc((void**)&dA, 2 * a * 8));
-    HIPCHK(hipMalloc((void**)&dB, 2 * b * 8));
-    HIPCHK(hipMalloc((void**)&ta, 3 * a * 8));
-    HIPCHK(hipMalloc((void**)&tb, 3 * b * 8));
-    HIPCHK(hipMalloc((void**)&dO, a * b * 8));
+    HIPCHK(tmp.get(&dA, (size_t)(2 * a * 8)));
+    HIPCHK(tmp.get(&dB, (size_t)(2 * b * 8)));
+    HIPCHK(tmp.get(&ta, (size_t)(3 * a * 8)));
+    HIPCHK(tmp.get(&tb, (size_t)(3 * b * 8)));
+    HIPCHK(tmp.get(&dO, (size_t)(a * b * 8)));
     HIPCHK(hipMemcpyAsync(dA, A, 2 * a * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dB, B, 2 * b * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, dA, a, h->metric, ta, ta + a, ta + 2 * a, nullptr);
@@ -605,11 +628,6 @@ static int dense_common(ck_handle* h, int bidx, int add_nugget, int mode, const 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dO, a * b * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(dA);
-    (void)hipFree(dB);
-    (void)hipFree(ta);
-    (void)hipFree(tb);
-    (void)hipFree(dO);
     return 0;
 }
 
@@ -631,16 +649,15 @@ extern "C" int ck_cov_lags(ck_handle* h, int i, int j, const double* lags, int64
     int bidx;
     if (blk_index(h, i, j, &bidx)) return -1;
     if (n <= 0) return 0;
+    DevTemps tmp;
     double *dl = nullptr, *dO = nullptr;
-    HIPCHK(hipMalloc((void**)&dl, n * 8));
-    HIPCHK(hipMalloc((void**)&dO, n * 8));
+    HIPCHK(tmp.get(&dl, (size_t)(n * 8)));
+    HIPCHK(tmp.get(&dO, (size_t)(n * 8)));
     HIPCHK(hipMemcpyAsync(dl, lags, n * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_cov_lags(h->stream, h->d_blk + bidx, (i == j) && use_nugget, dl, n, dO);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dO, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(dl);
-    (void)hipFree(dO);
     return 0;
 }
 
@@ -658,12 +675,18 @@ extern "C" int ck_model_variogram(ck_handle* h, const int32_t* pi, const int32_t
     double sill = h->blk[0].amp + h->blk[0].nugget;
     if (h->n_procs == 2) sill = 0.5 * (sill + (h->blk[2].amp + h->blk[2].nugget));
     else sill = 0.5 * sill;
-    int *di = nullptr, *dj = nullptr;
-    double *dl = nullptr, *dO = nullptr;
-    HIPCHK(hipMalloc((void**)&di, n * 4));
-    HIPCHK(hipMalloc((void**)&dj, n * 4));
-    HIPCHK(hipMalloc((void**)&dl, n * 8));
-    HIPCHK(hipMalloc((void**)&dO, n * 8));
+    if (n > h->mv_cap) {   // one allocation for all four arrays; a fit calls this hundreds of times with the same n
+        if (h->mv_buf) (void)hipFree(h->mv_buf);
+        h->mv_buf = nullptr;
+        h->mv_cap = 0;
+        const int64_t cap = roundup(n, 256);
+        HIPCHK(hipMalloc((void**)&h->mv_buf, (size_t)cap * 24));
+        h->mv_cap = cap;
+    }
+    double* dl = reinterpret_cast<double*>(h->mv_buf);
+    double* dO = dl + h->mv_cap;
+    int* di = reinterpret_cast<int*>(dO + h->mv_cap);
+    int* dj = di + h->mv_cap;
     HIPCHK(hipMemcpyAsync(di, pi, n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dj, pj, n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dl, lags, n * 8, hipMemcpyHostToDevice, h->stream));
@@ -671,10 +694,6 @@ extern "C" int ck_model_variogram(ck_handle* h, const int32_t* pi, const int32_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dO, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(di);
-    (void)hipFree(dj);
-    (void)hipFree(dl);
-    (void)hipFree(dO);
     return 0;
 }
 
@@ -815,7 +834,7 @@ static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
         if (ncols > 0) {
             const int64_t ra = r1 / CK_BM * CK_BM;   // tile-aligned start row (rows above r1 only touch the unused upper triangle)
             ck_launch_gemm_nt(st, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
-                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0, h->gemm_variant);
+                              P + r1 * CK_NB + q * CK_IB, CK_NB, R - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
         }
     }
 }
@@ -826,11 +845,9 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     while (J0 <= Jhi && (J0 % h->world) != h->rank) ++J0;
     if (J0 > Jhi) return;
     const int nJ = (Jhi - J0) / h->world + 1;
+    (void)P;   // the group kernel reads panel K through d_panelptr[K] (own storage or receive buffer)
     if (timed) gemm_timed_begin(h, st);
-    if (h->gemm_variant == 7 || h->gemm_variant == 8)   // the LDS-DMA tile with one panel (P is d_panelptr[K])
-        ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad, h->gemm_variant);
-    else
-        ck_launch_syrk_panels(st, h->d_sigptr, P, K, J0, h->world, nJ, h->Npad, h->gemm_variant);
+    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -859,7 +876,7 @@ static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
         const int64_t ncols = CK_NB - r1;
         if (ncols > 0)
             ck_launch_gemm_nt(st, X + r1, CK_NB, X + q * CK_IB, CK_NB, P + r1 * CK_NB + q * CK_IB, CK_NB, rows,
-                              ncols, CK_IB, 0, 0, 1, 0, 0, 0, h->gemm_variant);
+                              ncols, CK_IB, 0, 0, 1, 0, 0, 0);
     }
 }
 
@@ -867,16 +884,11 @@ static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
 static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi, hipStream_t st, bool timed) {
     const int nJ = Jhi - Jlo + 1;
     if (nJ <= 0) return;
-    double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     const int64_t rows = aux_rows(h, K);
     timed = timed && h->time_gemm == 1;   // 2: only the Sigma updates are timed (one event list per sweep)
+    (void)P;
     if (timed) gemm_timed_begin(h, st);
-    if (h->gemm_variant == 7 || h->gemm_variant == 8)
-        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, h->gemm_variant, rows);
-    else
-        ck_launch_gemm_nt(st, X + (int64_t)(Jlo - K) * h->mpad * CK_NB, CK_NB, X, CK_NB,
-                          P + (int64_t)(Jlo - K) * CK_NB * CK_NB, CK_NB, rows, CK_NB, CK_NB, 0, 0, nJ,
-                          h->mpad * CK_NB, 0, (int64_t)CK_NB * CK_NB, h->gemm_variant);
+    ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, rows);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -972,14 +984,14 @@ static int factor_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad, h->gemm_variant);
+                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad);
                     gemm_timed_end(h);
                 }
                 panel_factor_on(h, K0 + g, h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad, h->gemm_variant);
+                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad);
                 gemm_timed_end(h);
             }
         }
@@ -1016,15 +1028,14 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, h->gemm_variant,
-                                        aux_rows(h, K0 + g - 1));
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1));
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, h->gemm_variant,
+                ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc,
                                     aux_rows(h, K0 + Gc - 1));
                 gemm_timed_end(h);
             }
@@ -1179,19 +1190,14 @@ extern "C" int ck_predict(ck_handle* h, int i, const double* pcoords, int64_t m,
     if (!h->factored) return fail("ck_factor has not been called");
     if (ck_aux_begin(h, i, pcoords, m)) return -1;
     h->gemm_ev_used = 0;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, h->stream));
+    HIPCHK(hipEventRecord(h->ev2, h->stream));   // the handle's second event pair: ev0 / ev1 are used inside
     if (solve_sweep(h)) return -1;
-    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventRecord(h->ev3, h->stream));
     if (ck_aux_finish(h, pred, pred_err)) return -1;
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, h->ev2, h->ev3));
     h->t_ms[3] = ms;
     gemm_timed_collect(h, 7);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     h->aux_state = 2;
     return 0;
 }
@@ -1374,9 +1380,10 @@ extern "C" int ck_sample(ck_handle* h, const double* noise, double* out, int64_t
     std::vector<double> hv(Np, 0.0), ho(Np);
     memcpy(hv.data(), noise, n0 * 8);
     if (n > n0) memcpy(hv.data() + h->n0p, noise + n0, (n - n0) * 8);
+    DevTemps tmp;
     double *dv = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void**)&dv, Np * 8));
-    HIPCHK(hipMalloc((void**)&dout, Np * 8));
+    HIPCHK(tmp.get(&dv, (size_t)(Np * 8)));
+    HIPCHK(tmp.get(&dout, (size_t)(Np * 8)));
     HIPCHK(hipMemcpyAsync(dv, hv.data(), Np * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_tri_matvec(h->stream, h->d_sigptr, Np, dv, dout);
     HIPCHK(hipGetLastError());
@@ -1384,8 +1391,6 @@ extern "C" int ck_sample(ck_handle* h, const double* noise, double* out, int64_t
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(out, ho.data(), n0 * 8);
     if (n > n0) memcpy(out + n0, ho.data() + n0 + gap, (n - n0) * 8);
-    (void)hipFree(dv);
-    (void)hipFree(dout);
     return 0;
 }
 
@@ -1454,17 +1459,18 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     if (k_max) *k_max = 0;
     if (m == 0) return 0;
     const int64_t mp = roundup(m, 64);
+    DevTemps tmp;
     double *d_pc = nullptr, *d_p3 = nullptr, *d_pu = nullptr, *d_out = nullptr, *d_slab = nullptr;
     int* d_cnt = nullptr;
     long long *d_off = nullptr, *d_linfo = nullptr;
     int* d_k0 = nullptr;
     CkLocalSys* d_sys = nullptr;
-    HIPCHK(hipMalloc((void**)&d_pc, 2 * mp * 8));
-    HIPCHK(hipMalloc((void**)&d_p3, 3 * mp * 8));
-    HIPCHK(hipMalloc((void**)&d_pu, 3 * mp * 8));
-    HIPCHK(hipMalloc((void**)&d_out, 2 * mp * 8));
-    HIPCHK(hipMalloc((void**)&d_cnt, mp * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&d_off, mp * sizeof(long long)));
+    HIPCHK(tmp.get(&d_pc, (size_t)(2 * mp * 8)));
+    HIPCHK(tmp.get(&d_p3, (size_t)(3 * mp * 8)));
+    HIPCHK(tmp.get(&d_pu, (size_t)(3 * mp * 8)));
+    HIPCHK(tmp.get(&d_out, (size_t)(2 * mp * 8)));
+    HIPCHK(tmp.get(&d_cnt, (size_t)(mp * sizeof(int))));
+    HIPCHK(tmp.get(&d_off, (size_t)(mp * sizeof(long long))));
     HIPCHK(hipMemsetAsync(d_pc, 0, 2 * mp * 8, h->stream));
     HIPCHK(hipMemcpyAsync(d_pc, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
     ck_launch_prep_sites(h->stream, d_pc, mp, h->metric, d_p3, d_p3 + mp, d_p3 + 2 * mp, d_pu);
@@ -1587,9 +1593,9 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
                               h->d_coefptr, use_tab, h->su, d_pu, k_hi, h->d_chunkb, cmax);
     HIPCHK(hipGetLastError());
     if (!tiled.empty()) {
-        HIPCHK(hipMalloc((void**)&d_sys, sysv.size() * sizeof(CkLocalSys)));
-        HIPCHK(hipMalloc((void**)&d_linfo, sysv.size() * sizeof(long long)));
-        HIPCHK(hipMalloc((void**)&d_k0, sysv.size() * sizeof(int)));
+        HIPCHK(tmp.get(&d_sys, (size_t)(sysv.size() * sizeof(CkLocalSys))));
+        HIPCHK(tmp.get(&d_linfo, (size_t)(sysv.size() * sizeof(long long))));
+        HIPCHK(tmp.get(&d_k0, (size_t)(sysv.size() * sizeof(int))));
         HIPCHK(hipMemcpyAsync(d_sys, sysv.data(), sysv.size() * sizeof(CkLocalSys), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemsetAsync(d_linfo, 0, sysv.size() * sizeof(long long), h->stream));
         for (const auto& tb : tbatches) {
@@ -1627,15 +1633,6 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     if (n_empty) *n_empty = nempty;
     if (n_not_pd) *n_not_pd = npd;
     if (k_max) *k_max = kmx;
-    (void)hipFree(d_pc);
-    (void)hipFree(d_p3);
-    (void)hipFree(d_pu);
-    (void)hipFree(d_out);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_off);
-    if (d_sys) (void)hipFree(d_sys);
-    if (d_linfo) (void)hipFree(d_linfo);
-    if (d_k0) (void)hipFree(d_k0);
     return 0;
 }
 
@@ -1680,15 +1677,15 @@ static int vario_upload(ck_handle* h, const double* coords, const double* vals, 
             host_vals[(size_t)k] = vals[e];
         }
     }
-    double* tmp = nullptr;
+    DevTemps tmp;
+    double* stage = nullptr;
     HIPCHK(hipMalloc((void**)u, 3 * n * 8));
     HIPCHK(hipMalloc((void**)v, n * 8));
-    HIPCHK(hipMalloc((void**)&tmp, 2 * n * 8));
-    HIPCHK(hipMemcpyAsync(tmp, host_coords.data(), 2 * n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(tmp.get(&stage, (size_t)(2 * n * 8)));
+    HIPCHK(hipMemcpyAsync(stage, host_coords.data(), 2 * n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(*v, host_vals.data(), n * 8, hipMemcpyHostToDevice, h->stream));
-    ck_launch_vario_prep(h->stream, tmp, n, h->metric, *u, *u + n, *u + 2 * n);
+    ck_launch_vario_prep(h->stream, stage, n, h->metric, *u, *u + n, *u + 2 * n);
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(tmp);
     return 0;
 }
 
@@ -2147,10 +2144,6 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->time_gemm = (int)value;
         return 0;
     }
-    if (!strcmp(name, "gemm_variant")) {   // A/B switch of the GEMM tile structure (this handle)
-        h->gemm_variant = (int)value;
-        return 0;
-    }
     if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
         h->lookahead = value != 0;
         return 0;
@@ -2224,7 +2217,7 @@ extern "C" int ck_dev_gemm_nt(ck_handle* h, double* C, int64_t ldc, const double
                               int64_t ldb, int64_t M, int64_t N, int64_t K, int lower) {
     CHKH(h);
     if (M % CK_BM || N % 64 || K % 16) return fail("ck_dev_gemm_nt: M % 256, N % 64, K % 16 must be 0");
-    ck_launch_gemm_nt(h->stream, C, ldc, A, lda, B, ldb, M, N, K, lower, 0, 1, 0, 0, 0, h->gemm_variant);
+    ck_launch_gemm_nt(h->stream, C, ldc, A, lda, B, ldb, M, N, K, lower, 0, 1, 0, 0, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }

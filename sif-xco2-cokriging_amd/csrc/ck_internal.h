@@ -69,27 +69,24 @@ void ck_launch_cov_lags(hipStream_t s, const CkMatern* blk_ij, int add_nugget, c
                         double* out);
 
 // ---- dense linear algebra (ck_la.hip) ----------------------------------------
-#define CK_GEMM_DEFAULT 7   // tile structure of the MFMA GEMMs (ck_la.hip); per handle through option "gemm_variant"
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T on FP64 MFMA.
 // M % 256 == 0, N % 64 == 0, K % 16 == 0.  lower: skip tiles whose rows are all above the
 // diagonal  row + diag_off == col.
 // batch > 1 repeats the product over blockIdx.y with element strides sC / sA / sB.
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
-                       int64_t sC, int64_t sA, int64_t sB, int variant);
+                       int64_t sC, int64_t sA, int64_t sB);
 // Cholesky trailing update of every owned block column J = J0 + y * Jstep (y < nJ) by panel K
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int variant);
+                          int Jstep, int nJ, int64_t Npad);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int variant, int64_t mrows);
+                         int nJ, int64_t mrows);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur
 // complement (ck_verify_model); aux: np block columns of mpad x CK_NB solved right-hand-side rows
 void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,
                           int64_t Mpad);
-void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
-                           int nJ, int64_t Npad, int variant);
 // In-place Cholesky of the 64 x 64 diagonal block at A (ld); info_dev gets global_index0 + j + 1 of
 // the first non-positive pivot (only if still 0).
 void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,

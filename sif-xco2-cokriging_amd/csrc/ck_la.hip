@@ -1,17 +1,20 @@
-// ck_la.hip -- dense FP64 linear algebra kernels for gfx950 (MI355X).
+// ck_la.hip -- dense FP64 linear algebra kernels for gfx950 (MI355X), all on v_mfma_f64_16x16x4_f64.
 //
-//   k_gemm_nt    C -= A B^T on v_mfma_f64_16x16x4_f64, LDS-tiled, register-prefetched.
-//                This is the trailing update of the blocked Cholesky (cho_factor,
-//                src/joint_prediction.py:69) and of the forward substitution
-//                (first half of cho_solve, src/joint_prediction.py:68-73): the one
-//                genuinely dense contraction on the path.
-//   k_potrf64    Cholesky of a 64 x 64 diagonal block in LDS (one workgroup).
-//   k_trsm64     X L^T = A for 64-column row slabs, one row per lane.
-//   k_reduce_pred  fused prediction / variance reductions (src/joint_prediction.py:74-78
-//                without the m x m matrix).
+//   gemm_tile_d      128 x 128 tile, 8 waves, LDS-DMA staging, K = 512 x (number of panels): the trailing updates of
+//                    the blocked Cholesky (cho_factor, src/joint_prediction.py:69: k_syrk_group_d), of the forward
+//                    substitution (first half of cho_solve, :68-73: k_aux_group_d) and of the Schur complement of
+//                    the prediction sites (_verify_model, :260-274: k_schur_syrk_d) -- the dense contractions of the path.
+//   gemm_tile_e      the same tile staged through registers for plain pointers and small K (k_gemm_nt_e: K = 64
+//                    updates inside a panel; k_lt_update: the local predictor's trailing updates).
+//   gemm_tile<2>     256 x 64 tile for the narrow panel-internal products (k_gemm_nt<2>).
+//   k_potrf64        Cholesky of a 64 x 64 diagonal block AND its inverse (one workgroup, register resident).
+//   k_trsm64m        row solves X L^T = A as a product with that inverse on the matrix cores.
+//   k_panel_* / lt_* fused 64-column steps (right-hand-side rows of a panel; local predictor's tiled path).
+//   k_reduce_pred    fused prediction / variance reductions (src/joint_prediction.py:74-78 without the m x m matrix).
+//   k_tri_matvec     z = L eps (sim.py:52-54);  k_loo_rows: unit right-hand sides of the leave-one-out sweep.
 //
-// All matrices are row-major.  Dimensions handed to these kernels are padded
-// by the host (ck_api.hip) so that no edge predication is needed in the hot loops.
+// All matrices are row-major.  Dimensions handed to these kernels are padded by the host (ck_api.hip) so that no
+// edge predication is needed in the hot loops.
 #include "ck_internal.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -191,155 +194,15 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 }
 
 // ---------------------------------------------------------------------------------------
-// 128 x 128 tile, 4 waves, two workgroups per CU (option "gemm_variant" = 4)
+// 128 x 128 tile, 8 waves of 64 x 32, register-staged (plain pointers, any K % 16 == 0)
 // ---------------------------------------------------------------------------------------
-// A tile's C traffic (load 128 KB, store 128 KB) cannot overlap its own MFMA work: the
-// accumulators are the C tile.  With ONE 256 x 128 workgroup per CU that traffic is exposed
-// (~20 % of the tile time at K = 512, measured: MFMA pipe 69 % busy).  Two independent
-// 128 x 128 workgroups per CU (64 KB LDS, 4 waves each, one wave of each per SIMD) drift out of
-// phase, so one's prologue / epilogue runs under the other's K loop -- and a single wave
-// saturates the f64 MFMA pipe.  Same "row image" LDS layout as the ping-pong tile
-// (slot = pair ^ ((row >> 1) & 7)), filled through registers (coalesced 128-byte rows).
-template <int DUMMY>
-__device__ __forceinline__ void gemm_tile_s(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
-                                            const double* __restrict__ B, long ldb, long r0, long c0, int K,
-                                            char* lds) {
-    constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
-    constexpr int STAGE = 256 * 128;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int li = lane & 15, g = lane >> 4;
-
-    const ck_gchar* Ab = as_global(reinterpret_cast<const char*>(A + r0 * lda));
-    const ck_gchar* Bb = as_global(reinterpret_cast<const char*>(B + c0 * ldb));
-    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
-    // staging: chunk (row = tid >> 3 (+32 u), pair p = tid & 7) -> slot p ^ ((row >> 1) & 7); row + 32 u keeps the swizzle
-    const int srow = tid >> 3, sp = tid & 7;
-    const unsigned a_src0 = (unsigned)(srow * (int)lda + sp * 2) * 8u;
-    const unsigned b_src0 = (unsigned)(srow * (int)ldb + sp * 2) * 8u;
-    const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
-    const long a_step = 32 * lda * 8, b_step = 32 * ldb * 8;   // bytes, wave-uniform
-    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * 64 + li) * 8u;
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int slot = (4 * kb + g) ^ (li >> 1);
-        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
-        b_rd[kb] = BOFF + (wn * 64 + li) * 128 + slot * 16;
-    }
-
-    d2_t ra[4], rb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * a_step + a_src0);
-        rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * b_step + b_src0);
-    }
-    d4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
-        }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        *reinterpret_cast<d2_t*>(lds + s_dst0 + u * 4096) = -ra[u];
-        *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * 4096) = rb[u];
-    }
-    __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
-    __syncthreads();
-#ifdef CK_EXPERIMENT_PHASE
-    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) __builtin_amdgcn_s_sleep(32);   // HW_ID.wave_id parity
-#endif
-
-    const int nst = K / GEMM_BK;
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        const bool more = (st + 1 < nst);
-        if (more) {
-            const long k0 = (long)(st + 1) * (GEMM_BK * 8);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * a_step) + a_src0);
-                rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * b_step) + b_src0);
-            }
-        }
-        const char* sb = lds + cur * STAGE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            d2_t af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            char* nx = lds + (cur ^ 1) * STAGE;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                *reinterpret_cast<d2_t*>(nx + s_dst0 + u * 4096) = -ra[u];
-                *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * 4096) = rb[u];
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
-        }
-}
-
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_s(double* __restrict__ C, long ldc, const double* __restrict__ A,
-                                                       long lda, const double* __restrict__ B, long ldb, int tiles_m,
-                                                       int tiles_n, int K, int lower, long diag_off, long sC, long sA,
-                                                       long sB) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
-    if (lower && r0 + 127 + diag_off < c0) return;
-    const long y = blockIdx.y;
-    gemm_tile_s<0>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
-}
-
-__global__ __launch_bounds__(256, 2) void k_syrk_panels_s(double* const* __restrict__ sigptr,
-                                                           const double* __restrict__ P, int K, int J0, int Jstep,
-                                                           long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int J = J0 + (int)blockIdx.y * Jstep;
-    const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
-    if (r0 + 127 < c0) return;
-    const double* A = P + (long)(J - K) * CK_NB * CK_NB;
-    gemm_tile_s<0>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
-}
-
-// ---------------------------------------------------------------------------------------
-// 128 x 128 tile, 8 waves of 64 x 32, two workgroups per CU (option "gemm_variant" = 5)
-// ---------------------------------------------------------------------------------------
-// Same tile, LDS image and K pipeline as gemm_tile_s, but each wave owns a 64 x 32 quarter-strip
-// (8 accumulator tiles = 64 VGPRs instead of 128), so the kernel fits 128 VGPRs and FOUR waves
-// share a SIMD: while one waits at the per-chunk barrier or on its fragment reads, three others
-// can feed the MFMA pipe (with gemm_tile_s it is one other).
+// The tile of the small-K products: the K = 64 panel-internal updates (k_gemm_nt_e) and the trailing updates
+// of the local predictor's tiled path (k_lt_update).  A tile's C traffic (load 128 KB, store 128 KB) cannot
+// overlap its own MFMA work -- the accumulators ARE the C tile -- so two independent workgroups share a CU
+// (64 KB of LDS each) and drift out of phase: one's prologue / epilogue runs under the other's K loop.  Each
+// wave owns a 64 x 32 quarter-strip (8 accumulator tiles = 64 VGPRs).  "Row image" LDS layout: 128-byte rows,
+// 16-byte k-pair p of row r in slot p ^ ((r >> 1) & 7), filled through registers (coalesced 128-byte global
+// rows, A negated on its way in), read with ds_read_b128 that hit every bank once per hardware lane group.
 template <int DUMMY>
 __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
                                             const double* __restrict__ B, long ldb, long r0, long c0, int K,
@@ -430,11 +293,16 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
         }
         __syncthreads();
     }
+    // The 16 row addresses are recomputed here from a laundered copy of the (wave-uniform) tile pointer: left to
+    // itself hipcc keeps the prologue's sixteen 64-bit row pointers alive in VGPRs across the K loop for reuse
+    // and, at the 128-VGPR budget of four waves per SIMD, spills them (22 VGPRs of scratch before this).
+    ck_gdouble* Ce = Cb;
+    asm volatile("" : "+s"(Ce));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
+            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Ce + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
             for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
         }
@@ -453,142 +321,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt_e(double* __restrict__ C, lo
     gemm_tile_e<0>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
 }
 
-__global__ __launch_bounds__(512, 4) void k_syrk_panels_e(double* const* __restrict__ sigptr,
-                                                           const double* __restrict__ P, int K, int J0, int Jstep,
-                                                           long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int J = J0 + (int)blockIdx.y * Jstep;
-    const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
-    if (r0 + 127 < c0) return;
-    const double* A = P + (long)(J - K) * CK_NB * CK_NB;
-    gemm_tile_e<0>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
-}
-
 // ---------------------------------------------------------------------------------------
 // Multi-panel K: C -= sum_p A_p B_p^T in ONE pass over the C tile (option "panel_group")
 // ---------------------------------------------------------------------------------------
-// With K = 512 per trailing update, the 128 x 128 tile spends ~7 % of its time loading and
-// storing C (accumulators = C tile; measured 61.7 TF at K = 512 against 65.5 at K = 2048 and 66.2
-// at K = 8192).  The factorisation therefore groups G panels (ck_api.hip: factor_sweep): the
-// trailing matrix beyond a group is updated once with K = 512 G, its A / B operands coming from G
-// different panel buffers.  Same tile, LDS image and chunk pipeline as gemm_tile_s / gemm_tile_e;
-// the source pointers change every 32 chunks (wave-uniform, scalar loads).
-//   WAVES = 4, TN = 128: 64 x 64 per wave, two workgroups per CU = 2 waves per SIMD (256 VGPRs)
-//   WAVES = 8, TN = 128: 64 x 32 per wave, two workgroups per CU = 4 waves per SIMD (128 VGPRs)
-//   WAVES = 4, TN = 64:  128 x 64 tile, 64 x 32 per wave, 48 KB of LDS: THREE workgroups per CU, i.e.
-//                        three waves per SIMD that belong to different workgroups and never wait
-//                        at the same barrier (with 8 waves per workgroup two of a SIMD's four do)
-// SRC::get(p, A, B): byte pointers to row r0 of A_p and row c0 of B_p (both ld = CK_NB doubles).
-template <int WAVES, int TN, class SRC>
-__device__ __forceinline__ void gemm_tile_m(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
-                                            char* lds) {
-    static_assert((WAVES == 4 && (TN == 128 || TN == 64)) || (WAVES == 8 && TN == 128), "tile shapes");
-    constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
-    constexpr int STAGE = (128 + TN) * 128;
-    constexpr int WCOLS = WAVES == 8 ? 4 : 2;    // waves across the tile's columns
-    constexpr int WJ = TN / WCOLS / 16;          // 16-column MFMA tiles per wave
-    constexpr int RSTEP = WAVES * 8;             // rows between a thread's pieces (threads / 8)
-    constexpr int NUA = 128 / RSTEP;             // staged 16-byte pieces per thread: A rows
-    constexpr int NUB = TN / RSTEP;              // ... B rows
-    constexpr int NST = CK_NB / GEMM_BK;         // chunks per panel
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wm = w / WCOLS, wn = w % WCOLS;
-    const int li = lane & 15, g = lane >> 4;
-
-    ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
-    const int srow = tid >> 3, sp = tid & 7;
-    const unsigned src0 = (unsigned)(srow * CK_NB + sp * 2) * 8u;
-    const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
-    constexpr long u_step = (long)RSTEP * CK_NB * 8;   // bytes
-    const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * (WJ * 16) + li) * 8u;
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int slot = (4 * kb + g) ^ (li >> 1);
-        a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
-        b_rd[kb] = BOFF + (wn * (WJ * 16) + li) * 128 + slot * 16;
-    }
-
-    const ck_gchar *Ab, *Bb;
-    src.get(0, Ab, Bb);
-    d2_t ra[NUA], rb[NUB];
-#pragma unroll
-    for (int u = 0; u < NUA; ++u) ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * u_step + src0);
-#pragma unroll
-    for (int u = 0; u < NUB; ++u) rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * u_step + src0);
-    d4_t acc[4][WJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
-        }
-#pragma unroll
-    for (int u = 0; u < NUA; ++u) *reinterpret_cast<d2_t*>(lds + s_dst0 + u * (RSTEP * 128)) = -ra[u];
-#pragma unroll
-    for (int u = 0; u < NUB; ++u) *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
-    __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
-    __syncthreads();
-
-    const int nst = np * NST;
-    int pnl = 0, kc = 0;             // panel and chunk-in-panel of the chunk being PREFETCHED
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        const bool more = (st + 1 < nst);
-        if (more) {
-            if (++kc == NST) {
-                kc = 0;
-                src.get(++pnl, Ab, Bb);
-            }
-            const long k0 = (long)kc * (GEMM_BK * 8);
-#pragma unroll
-            for (int u = 0; u < NUA; ++u) ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * u_step) + src0);
-#pragma unroll
-            for (int u = 0; u < NUB; ++u) rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * u_step) + src0);
-        }
-        const char* sb = lds + cur * STAGE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            d2_t af[4], bf[WJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < WJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            char* nx = lds + (cur ^ 1) * STAGE;
-#pragma unroll
-            for (int u = 0; u < NUA; ++u) *reinterpret_cast<d2_t*>(nx + s_dst0 + u * (RSTEP * 128)) = -ra[u];
-#pragma unroll
-            for (int u = 0; u < NUB; ++u) *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * (RSTEP * 128)) = rb[u];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
-        }
-}
+// With K = 512 per trailing update, a 128 x 128 tile spends ~7 % of its time loading and storing C
+// (accumulators = C tile; measured 61.7 TF at K = 512 against 65.5 at K = 2048 and 66.2 at K = 8192).  The
+// factorisation therefore groups G panels (ck_api.hip: factor_sweep): the trailing matrix beyond a group is
+// updated once with K = 512 G, its A / B operands coming from G different panel buffers: the source pointers
+// change every 32 chunks (wave-uniform, scalar loads).  SRC::get(p, A, B): byte pointers to row r0 of A_p and
+// row c0 of B_p (both ld = CK_NB doubles).
 
 // operands of the grouped Cholesky trailing update: panels K0 .. K0 + np - 1, block column J.
 // sigptr[K]: where panel K can be READ on this rank (its own storage, or the receive buffer a remote
@@ -618,19 +359,21 @@ struct CkSrcAux {
 };
 
 // ---------------------------------------------------------------------------------------
-// The 8-wave multi-panel tile with LDS-DMA staging (option "gemm_variant" = 7)
+// The multi-panel tile: 128 x 128, 8 waves of 64 x 32, LDS-DMA staging -- the trailing updates of the
+// factorisation, of the solve sweep and of the Schur complement
 // ---------------------------------------------------------------------------------------
-// gemm_tile_m<8, 128> moves every operand byte global -> VGPR -> (negate) -> ds_write -> LDS and
-// waits for the writes in front of each barrier.  Here the next chunk goes global -> LDS directly
-// (global_load_lds_dwordx4: one wave instruction fills 8 whole 128-byte rows, 1 KB linear in LDS;
-// the row-image swizzle is applied on the GLOBAL side: lane (row r8, slot sj) fetches pair
-// sj ^ ((row >> 1) & 7), so the global side stays one full line per row).  No staging registers, no
-// ds_write, no sign flips in the loop: the accumulators start as -C and are stored as -acc.
-// The freed registers hold the second half-chunk's fragments, read under the first half's MFMAs.
+// The next chunk goes global -> LDS directly (global_load_lds_dwordx4: one wave instruction fills 8 whole
+// 128-byte rows, 1 KB linear in LDS; the row-image swizzle is applied on the GLOBAL side: lane (row r8, slot sj)
+// fetches pair sj ^ ((row >> 1) & 7), so the global side stays one full line per row).  No staging registers, no
+// ds_write, no sign flips in the loop: the accumulators start as -C and are stored as -acc.  Against the same
+// tile staged through registers (global -> VGPR -> negate -> ds_write, waited for in front of each barrier):
+// -10 ms in the factorisation and -8 ms in the solve sweep at N = 40 000.  Tile structures measured and retired
+// (DESIGN.md section 5 keeps their numbers): 4 waves of 64 x 64 (register- and DMA-staged), 128 x 64 tiles with
+// three workgroups per CU, one 256 x 128 workgroup per CU, padded LDS rows, a ping-pong schedule.
 template <int WAVES, class SRC>
 __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
                                             char* lds) {
-    static_assert(WAVES == 8 || WAVES == 4, "8 waves of 64 x 32 or 4 waves of 64 x 64");
+    static_assert(WAVES == 8, "8 waves of 64 x 32");
     constexpr int BOFF = 128 * 128;
     constexpr int STAGE = 256 * 128;
     constexpr int NST = CK_NB / GEMM_BK;
@@ -697,9 +440,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
                 kc = 0;
                 src.get(++pnl, Ab, Bb);
             }
-#ifndef CK_EXP_NODMA
             CK_DMA_CHUNK(cur ^ 1, (long)kc * (GEMM_BK * 8));
-#endif
         }
         const char* sb = lds + cur * STAGE;
         d2_t af[2][4], bf[2][WJ];
@@ -710,7 +451,6 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 #pragma unroll
             for (int j = 0; j < WJ; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
         }
-        if (WAVES == 4) __builtin_amdgcn_sched_barrier(0);   // both half-chunks' fragments in flight before the first MFMA
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -721,9 +461,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
                     for (int j = 0; j < WJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb][i][h], bf[kb][j][h], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next chunk is in LDS
-#ifndef CK_EXP_NOBARRIER
         __syncthreads();
-#endif
     }
 #undef CK_DMA_CHUNK
 #pragma unroll
@@ -809,84 +547,23 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
     k_schur_syrk_d<<<grid, dim3(512), 0, s>>>(schur_dev, aux, mpad, np, Mpad);
 }
 
-// block columns J = J0 + blockIdx.y (all owned: single-process form) -= sum over panels K0 .. K0 + np - 1
-template <int WAVES, int TN>
-__global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_syrk_group(
-    double* const* __restrict__ sigptr, int K0, int np, int J0, long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * (128 + TN) * 128];
-    const int J = J0 + (int)blockIdx.y;
-    const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / TN;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * TN;
-    if (r0 + 127 < c0) return;
-    const CkSrcSyrk src{sigptr, K0, J, r0, c0};
-    gemm_tile_m<WAVES, TN>(sigptr[J], CK_NB, src, np, r0, c0, lds);
-}
-
-// aux block columns J = J0 + blockIdx.y -= sum over p of aux[K0 + p] L[J, K0 + p]^T
-template <int WAVES, int TN>
-__global__ __launch_bounds__(WAVES * 64, TN == 64 ? 3 : (WAVES == 4 ? 2 : 4)) void k_aux_group(
-    double* __restrict__ aux, long mpad, double* const* __restrict__ sigptr, int K0, int np, int J0, long mrows) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * (128 + TN) * 128];
-    const int J = J0 + (int)blockIdx.y;
-    const int tiles_n = CK_NB / TN;
-    const int nblk = (int)(mrows / 128) * tiles_n;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * 128, c0 = (long)tn * TN;
-    const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
-    gemm_tile_m<WAVES, TN>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
-}
-
-// srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 (the
-// block-column-cyclic stride of a multi-process run) is served by the LDS-DMA form only
+// srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the
+// block-column-cyclic stride of a multi-process run
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int variant) {
+                          int Jstep, int nJ, int64_t Npad) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
-    if (variant == 6) {
-        const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 64)), (unsigned)nJ);
-        k_syrk_group<4, 64><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
-        return;
-    }
-    if (variant == 7 || variant == 8) {
-        const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-        if (variant == 7)
-            k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
-        else
-            k_syrk_group_d<4><<<grid, dim3(256), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
-        return;
-    }
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (variant == 4)
-        k_syrk_group<4, 128><<<grid, dim3(256), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
-    else
-        k_syrk_group<8, 128><<<grid, dim3(512), 0, s>>>(sigptr_dev, K0, np, J0, Npad);
+    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
 }
 
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
 // sweep knows that the others are still zero in these columns
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int variant, int64_t mrows) {
+                         int nJ, int64_t mrows) {
     if (nJ <= 0 || np <= 0 || mrows <= 0) return;
-    if (variant == 6) {
-        const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 64)), (unsigned)nJ);
-        k_aux_group<4, 64><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
-        return;
-    }
     const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 128)), (unsigned)nJ);
-    if (variant == 7)
-        k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
-    else if (variant == 8)
-        k_aux_group_d<4><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
-    else if (variant == 4)
-        k_aux_group<4, 128><<<grid, dim3(256), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
-    else
-        k_aux_group<8, 128><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
+    k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
 }
 
 // plain (optionally batched over blockIdx.y) form
@@ -905,79 +582,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt(double* __restrict__ C, long
     gemm_tile<WN>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
 }
 
-// Trailing update of the Cholesky for ALL locally owned block columns J > K in one launch:
-//   sig[J] (rows J*NB.., NB cols) -= P[(J-K)*NB.., :] * P[(J-K)*NB .. (J-K+1)*NB, :]^T
-// where P is the factored panel K (rows K*NB.. of L, NB columns, ld = NB).
-// blockIdx.y enumerates the owned J = J0 + y * Jstep; blockIdx.x the tiles of the largest one.
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void k_syrk_panels(double* const* __restrict__ sigptr,
-                                                         const double* __restrict__ P, int K, int J0, int Jstep,
-                                                         long Npad) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 8 * (CK_BM + 128) * 16];
-    const int J = J0 + (int)blockIdx.y * Jstep;
-    const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / CK_BM), tiles_n = CK_NB / 128;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long r0 = (long)tm * CK_BM, c0 = (long)tn * 128;
-    if (r0 + (CK_BM - 1) < c0) return;
-    const double* A = P + (long)(J - K) * CK_NB * CK_NB;
-    gemm_tile<4>(sigptr[J], CK_NB, A, CK_NB, A, CK_NB, r0, c0, CK_NB, lds);
-}
-
-// Tile structures (handle option "gemm_variant", A/B tests; CK_GEMM_DEFAULT in ck_internal.h):
-//   7: 128x128 tiles, 8 waves of 64x32, LDS-DMA staging, two workgroups per CU (default)
-//   5: the same staged through registers      4: 4 waves of 64x64 through registers
-//   8: 4 waves of 64x64, LDS-DMA              6: 128x64 tiles, three workgroups per CU
-//   0: one 256x128 workgroup per CU
-
+// N % 128 == 0: 128 x 128 tiles (gemm_tile_e); otherwise (N a multiple of 64 only: the narrow right-hand sides of
+// the panel-internal K = 64 updates) 256 x 64 tiles (gemm_tile<2>)
 void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, int lower, int64_t diag_off, int batch,
-                       int64_t sC, int64_t sA, int64_t sB, int variant) {
+                       int64_t sC, int64_t sA, int64_t sB) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return;
-    const int v = variant;
-    if ((v == 5 || v == 6 || v == 7 || v == 8) && N % 128 == 0) {
+    if (N % 128 == 0 && M % 128 == 0) {
         const int tm = (int)(M / 128), tn = (int)(N / 128);
         k_gemm_nt_e<<<dim3(tm * tn, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
                                                              sC, sA, sB);
         return;
     }
-    if ((v == 4 || v == 5) && N % 128 == 0) {
-        const int tm = (int)(M / 128), tn = (int)(N / 128);
-        k_gemm_nt_s<<<dim3(tm * tn, batch), dim3(256), 0, s>>>(C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower, diag_off,
-                                                             sC, sA, sB);
-        return;
-    }
-    const int tiles_m = (int)(M / CK_BM);
-    if (N % 128 == 0) {
-        const int tiles_n = (int)(N / 128);
-        k_gemm_nt<4><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K,
-                                                                        lower, diag_off, sC, sA, sB);
-    } else {   // narrow right-hand sides (N a multiple of 64 only): the panel-internal K = 64 updates
-        const int tiles_n = (int)(N / 64);
-        k_gemm_nt<2><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K,
-                                                                        lower, diag_off, sC, sA, sB);
-    }
-}
-
-void ck_launch_syrk_panels(hipStream_t s, double* const* sigptr_dev, const double* P, int K, int J0, int Jstep,
-                           int nJ, int64_t Npad, int variant) {
-    if (nJ <= 0) return;
-    const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
-    const int maxblk = (int)(M0 / CK_BM) * (CK_NB / 128);
-    if (variant >= 5 && variant <= 8) {
-        k_syrk_panels_e<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
-                                                                                      Npad);
-        return;
-    }
-    if (variant == 4) {
-        k_syrk_panels_s<<<dim3((int)(M0 / 128) * (CK_NB / 128), nJ), dim3(256), 0, s>>>(sigptr_dev, P, K, J0, Jstep,
-                                                                                      Npad);
-        return;
-    }
-    k_syrk_panels<0><<<dim3(maxblk, nJ), dim3(512), 0, s>>>(sigptr_dev, P, K, J0, Jstep, Npad);
+    const int tiles_m = (int)(M / CK_BM), tiles_n = (int)(N / 64);
+    k_gemm_nt<2><<<dim3(tiles_m * tiles_n, batch), dim3(512), 0, s>>>(C, ldc, A, lda, B, ldb, tiles_m, tiles_n, (int)K,
+                                                                    lower, diag_off, sC, sA, sB);
 }
 
 // ---------------------------------------------------------------------------------------

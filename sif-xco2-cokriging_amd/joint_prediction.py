@@ -65,6 +65,7 @@ class Predictor:
         self.verify_model = None
         self.verify_max_points = 16384
         self._h = None
+        self._key = None
         self._verdict = None
 
     # -- device state -------------------------------------------------------------------------
@@ -91,11 +92,35 @@ class Predictor:
             # scipy.linalg.cho_factor's message (raised uncaught at src/joint_prediction.py:69)
             raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
 
+    def _state_key(self):
+        """What the resident factor depends on: the model's parameters, the metric, and the data arrays.  The
+        reference re-reads `mod.params` and `mf` on every __call__ (src/joint_prediction.py:50-55); here the factor
+        is reused only while none of them has changed (mod.fit(...), params.set_values(...), new fields -> refactor)."""
+        from .model import model_arrays
+        n, sig, nu, ls, nug, rho = model_arrays(self.mod)
+        key = [n, sig.tobytes(), nu.tobytes(), ls.tobytes(), nug.tobytes(), float(rho),
+               metric_of(self.dist_units, self.fast_dist)]
+        for k in range(self.n_procs):
+            f = self.mf.fields[k]
+            c = np.ascontiguousarray(f.coords_main, dtype=np.float64)
+            v = np.ascontiguousarray(f.values_main, dtype=np.float64)
+            key += [c.shape, hash(c.tobytes()), hash(v.tobytes())]
+        return tuple(key)
+
+    def invalidate(self):
+        """Drop the resident factor (it is rebuilt on the next call)."""
+        if self._h is not None:
+            self._h.close()
+        self._h, self._key = None, None
+
     def _factored_handle(self):
+        key = self._state_key()
+        if self._h is not None and key != self._key:
+            self.invalidate()
         if self._h is None:
             h = self._new_handle()
             self._factor(h)
-            self._h = h
+            self._h, self._key = h, key
         return self._h
 
     def predict_arrays(self, i: int, pcoords, cv_ix: int = None):
@@ -241,6 +266,9 @@ class Predictor:
         else:
             data["pred"], data["pred_err"] = pred, err
         data["residual"] = data["data"] - data["pred"]
+        # the reference's xr.merge(...).to_dataframe() + outer merge hands the rows back sorted by the coordinates
+        # (src/joint_prediction.py:248-254)
+        data = data.sort_values(names, kind="stable").reset_index(drop=True)
         return data[names + ["data", "pred", "residual", "pred_err"]]
 
 

@@ -163,13 +163,16 @@ class MultivariateMatern:
         return self._eval(i, j, h, False)
 
     def correlation(self, i: int, j: int, h) -> np.ndarray:
-        """src/model.py:188-191."""
+        """Matern correlation with (nu_ij, len_scale_ij) -- src/model.py:188-191; it does not depend on sigma or
+        rho, so it is evaluated with unit amplitudes (rho_12 = 0 is a valid model and must not divide by zero)."""
         if i > j:
             i, j = j, i
-        if i == j:
-            return self._eval(i, i, h, False) / self.params.sigma.values[i, i] ** 2
-        amp = self.params.rho.values[i, j] * np.nanprod(self.params.sigma.values)
-        return self._eval(i, j, h, False) / amp
+        n, sig, nu, ls, nug, rho = model_arrays(self)
+        if self._h is None:
+            self._h = native.Handle(self._device)
+        self._h.set_model(n, np.ones_like(sig), nu, ls, np.zeros_like(nug), 1.0)
+        h = np.atleast_1d(np.asarray(h, dtype=np.float64))
+        return self._h.cov_lags(i, j, h, use_nugget=False)   # the next _handle() call restores the model's amplitudes
 
     def semivariance(self, i: int, h) -> np.ndarray:
         """src/model.py:209-213."""

@@ -12,7 +12,8 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcokrige_hip.so")
+# CK_LIB_PATH: load another build of the library (kernel experiments) instead of overwriting the product one
+LIB_PATH = os.environ.get("CK_LIB_PATH") or os.path.join(HERE, "libcokrige_hip.so")
 
 METRIC_HAVERSINE = 0
 METRIC_EUCLID = 1

@@ -39,8 +39,14 @@ class Predictor:
         self.cv = False  # placeholder for cross-validation (src/point_prediction.py:43)
         self.info = {}
         self._h = None
+        self._key = None
 
     def _handle(self):
+        key = _JointPredictor._state_key(self)   # model parameters, metric, data: a change rebuilds the device state
+        if self._h is not None and key != self._key:
+            self._h.close()
+            self._h = None
+        self._key = key
         if self._h is None:
             h = native.Handle(self.device)
             configure_handle(h, self.mod)

@@ -98,14 +98,12 @@ def test_cov_dense_blocks(native, tag):
         np.testing.assert_allclose(c0, g[f"c0_{tag}_{i}"], rtol=5e-13, atol=1e-300)
 
 
-@pytest.mark.parametrize("variant", [7, 5, 4, 0])
-def test_gemm_nt_mfma(native, variant):
-    """every tile structure of the MFMA GEMM (option gemm_variant) against torch fp64"""
+def test_gemm_nt_mfma(native):
+    """the plain MFMA GEMM entry (128 x 128 register-staged tile; 256 x 64 tile for narrow N) against torch fp64"""
     import torch
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
     h = native.Handle(0)
-    h.set_option("gemm_variant", variant)
     for (M, N, K, lower) in ((256, 128, 16, False), (512, 256, 64, False), (768, 192, 64, False),
                              (1024, 512, 512, True), (256, 64, 64, False)):
         A = torch.randn(M, K, dtype=torch.float64, device=dev)
@@ -120,7 +118,7 @@ def test_gemm_nt_mfma(native, variant):
         if lower:
             # tiles strictly above the diagonal are skipped (left untouched)
             BN = 128 if N % 128 == 0 else 64
-            BM = 128 if (variant in (4, 5, 7) and N % 128 == 0) else 256
+            BM = 128 if N % 128 == 0 else 256
             c0 = C0.cpu().numpy()
             for tm in range(M // BM):
                 for tn in range(N // BN):
@@ -304,9 +302,13 @@ def test_joint_loocv(native, refactor_each):
     P = joint_prediction.Predictor(mod, mf)
     for i in (0, 1):
         df = P.cross_validation(i, postprocess=False, refactor_each=refactor_each)
-        assert rel(df["pred"].values, g[f"pred_{i}"]) < 1e-9
-        assert rel(df["pred_err"].values, g[f"pred_err_{i}"]) < 1e-9
-        np.testing.assert_allclose(df["residual"].values, g[f"values{i}"] - g[f"pred_{i}"], rtol=1e-7, atol=1e-9)
+        # rows come back sorted by the coordinates, like the reference's xr.merge + outer merge (:248-254)
+        c = g[f"coords{i}"]
+        o = np.lexsort((c[:, 1], c[:, 0]))
+        np.testing.assert_array_equal(df[["d1", "d2"]].values, c[o])
+        assert rel(df["pred"].values, g[f"pred_{i}"][o]) < 1e-9
+        assert rel(df["pred_err"].values, g[f"pred_err_{i}"][o]) < 1e-9
+        np.testing.assert_allclose(df["residual"].values, (g[f"values{i}"] - g[f"pred_{i}"])[o], rtol=1e-7, atol=1e-9)
 
 
 def test_sim_field_draw(native):
@@ -511,3 +513,63 @@ def test_verify_model_matches_reference(native):
     P.verify_model = False
     P.predict_arrays(1, pc)
     assert P._verdict is None
+
+
+class _StubTrend:
+    """stands in for the sklearn LinearRegression the reference stores in ds.attrs["spatial_model"] (src/fields.py:345-375)"""
+
+    def __init__(self, coef, intercept):
+        self.coef, self.intercept = np.asarray(coef, dtype=float), float(intercept)
+
+    def predict(self, X):
+        return np.asarray(X, dtype=float) @ self.coef + self.intercept
+
+
+class _Attrs:
+    def __init__(self, attrs):
+        self.attrs = attrs
+
+
+def test_postprocess_and_stale_state(native):
+    """postprocess=True (src/joint_prediction.py:155-205): rescale by scale_fact, add spatial_mean, the OLS spatial trend
+    of the standardised [lon, lat] covariates and the temporal trend -- against the same arithmetic done by hand on
+    the postprocess=False output.  Then: parameters changed after the first call are NOT ignored (the reference
+    re-reads mod.params on every call)."""
+    import pandas as pd
+    from sif_xco2_cokriging_amd import fields, joint_prediction, model
+    g = load_golden("joint_solve")
+    mod = model.MultivariateMatern(params=model.MaternParams().set_values(g["params_A"]))
+    f0, f1 = fields.Field(g["coords0_A"], g["values0_A"]), fields.Field(g["coords1_A"], g["values1_A"])
+    at = dict(scale_fact=1.7, spatial_mean=0.25, temporal_trend=-0.4, covariate_means=[-95.0, 37.0],
+              covariate_scales=[12.0, 6.0], spatial_model=_StubTrend([0.3, -0.2], 0.05))
+    for f in (f0, f1):
+        f.ds = _Attrs(at)
+        f.timestamp = "2020-07-01"
+    mf = fields.MultiField([f0, f1])
+    P = joint_prediction.Predictor(mod, mf)
+    pc = pd.DataFrame(g["pcoords_A"][6:], columns=["lat", "lon"])     # rows 0..5 sit on data sites
+    raw = P(1, pc, postprocess=False)
+    raw = raw.to_dataframe().reset_index() if hasattr(raw, "to_dataframe") else raw.reset_index()
+    raw = pc.merge(raw, on=["lat", "lon"], how="left")
+    out = P(1, pc, postprocess=True)
+    out = out.to_dataframe().reset_index() if hasattr(out, "to_dataframe") else out.reset_index()
+    out = pc.merge(out, on=["lat", "lon"], how="left")
+    trend = at["spatial_model"].predict(np.column_stack([(pc["lon"] - at["covariate_means"][0]) / at["covariate_scales"][0],
+                                                         (pc["lat"] - at["covariate_means"][1]) / at["covariate_scales"][1]]))
+    np.testing.assert_allclose(out["pred"].values, raw["pred"].values * 1.7 + 0.25 + trend - 0.4, rtol=1e-13)
+    np.testing.assert_allclose(out["pred_err"].values, raw["pred_err"].values * 1.7, rtol=1e-13)
+    assert rel(raw["pred"].values, g["pred_A_1"][6:]) < 1e-9
+    # stale state: new parameters -> new factor, new numbers (== a fresh Predictor's)
+    mod.params.set_values(g["params_R"])
+    again = P.predict_arrays(1, pc.values)
+    fresh = joint_prediction.Predictor(mod, mf).predict_arrays(1, pc.values)
+    assert np.array_equal(again[0], fresh[0]) and np.array_equal(again[1], fresh[1])
+    assert rel(again[0], raw["pred"].values) > 1e-6
+    # correlation does not depend on rho: rho_12 = 0 must not divide by zero (src/model.py:188-191)
+    vals = np.array(g["params_A"], dtype=float)
+    vals[-1] = 0.0
+    m0 = model.MultivariateMatern(params=model.MaternParams().set_values(vals))
+    hlag = np.array([0.0, 10.0, 300.0])
+    po = orc.Params.from_flat(g["params_A"])
+    np.testing.assert_allclose(m0.correlation(0, 1, hlag), orc.matern_correlation(po.nu[0, 1], po.len_scale[0, 1], hlag), rtol=5e-13)
+    np.testing.assert_allclose(m0.cross_covariance(0, 1, hlag), 0.0, atol=0)
