@@ -52,6 +52,10 @@ class _Marks:
         import time
         return time.perf_counter()
 
+    def wait(self, e):
+        if self.cuda:
+            e.synchronize()
+
     def ms(self, a, b):
         return float(a.elapsed_time(b)) if self.cuda else (b - a) * 1e3
 
@@ -168,6 +172,7 @@ class DistributedJoint:
         pred_l, err_l = h.aux_finish()
         info = h.factor_info()
         td = mk()
+        self._marks.wait(td)
         ms = self._marks.ms
         tm = {"assemble_ms": ms(ta, tb), "finish_ms": ms(tc, td), "panel_ms": 0.0, "update_ms": 0.0, "bcast_wait_ms": 0.0}
         for st in self._steps:
