@@ -223,7 +223,8 @@ def main():
             return h.predict(0, pb["pcoords"])
     else:
         from sif_xco2_cokriging_amd import distributed
-        runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank))
+        runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank),
+                                              exchange=os.environ.get("CK_PANEL_EXCHANGE", "broadcast"))
         runner.prepare(m_total=m)
         h.set_option("time_gemm", 2)   # HIP events around this rank's Sigma trailing-update launches
 
@@ -286,7 +287,8 @@ def main():
         if per_rank is not None:
             nK = -(-N // 512)
             out["per_rank"] = per_rank
-            out["comm"] = {"collective": "panel broadcast (RCCL over xGMI), one per 512-column panel, look-ahead depth 1",
+            out["comm"] = {"collective": ("panel scatter + point-to-point all-gather (CK_PANEL_EXCHANGE=p2p)" if runner.exchange == "p2p" and world > 2
+                                          else "panel broadcast (RCCL over xGMI)") + ", one per 512-column panel, look-ahead depth 1",
                            "panels": nK, "bytes_received_per_rank_per_step": int(sum((nK * 512 - K * 512) * 512 * 8 + 8 * 64 * 64 * 8
                                                                                      for K in range(nK) if K % world != 0)),
                            "note": "bcast_wait_ms = time the rank's stream waited for a panel after its own updates were done "

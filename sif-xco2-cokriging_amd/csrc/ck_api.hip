@@ -815,6 +815,28 @@ static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
     double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
+    if (h->panel_fused & 4) {
+        // The 512 x 512 diagonal block first -- right-looking over its eight 64-column sub-blocks, on its own 512
+        // rows only (small launches: 64 x 64 Cholesky + inverse, row solves, K = 64 update) -- then every row below
+        // it walks through the factored block on its own, in ONE launch (the kernel of the right-hand-side rows):
+        // 25 launches per panel, 24 of them on 512 rows, instead of 24 launches over all rows of the panel.
+        const int64_t RD = std::min<int64_t>(R, CK_NB);
+        for (int q = 0; q < CK_NB / CK_IB; ++q) {
+            double* diag = P + (int64_t)q * CK_IB * CK_NB + q * CK_IB;
+            double* linv = tail + (int64_t)q * CK_IB * CK_IB;
+            ck_launch_potrf64(st, diag, CK_NB, (int64_t)K * CK_NB + q * CK_IB, h->d_info, linv);
+            const int64_t r1 = (int64_t)(q + 1) * CK_IB;
+            if (RD > r1) ck_launch_trsm64(st, P + r1 * CK_NB + q * CK_IB, CK_NB, RD - r1, linv);
+            const int64_t ncols = CK_NB - r1;
+            if (ncols > 0 && RD > r1) {
+                const int64_t ra = r1 / CK_BM * CK_BM;
+                ck_launch_gemm_nt(st, P + ra * CK_NB + r1, CK_NB, P + ra * CK_NB + q * CK_IB, CK_NB,
+                                  P + r1 * CK_NB + q * CK_IB, CK_NB, RD - ra, ncols, CK_IB, 1, ra - r1, 1, 0, 0, 0);
+            }
+        }
+        if (R > CK_NB) ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail);
+        return;
+    }
     if (h->panel_fused & 1) {
         for (int q = 0; q < CK_NB / CK_IB; ++q) {
             double* linv = tail + (int64_t)q * CK_IB * CK_IB;
@@ -2154,7 +2176,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "panel_fused")) {   // see ck_handle::panel_fused
-        if (value < 0 || value > 3) return fail("panel_fused must be in [0, 3]");
+        if (value < 0 || value > 7) return fail("panel_fused must be in [0, 7]");
         h->panel_fused = (int)value;
         return 0;
     }

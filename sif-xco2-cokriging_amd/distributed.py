@@ -60,11 +60,32 @@ class _Marks:
         return float(a.elapsed_time(b)) if self.cuda else (b - a) * 1e3
 
 
+class _Works:
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
 class DistributedJoint:
-    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True):
+    """exchange = "broadcast": one collective broadcast per panel (RCCL picks ring / tree: every hop carries the whole
+    panel, so a step costs panel_bytes / one link).  exchange = "p2p": the owner SCATTERS the panel -- piece r to rank r,
+    seven pieces leaving on seven xGMI links at once -- and the ranks then exchange their pieces all-to-all by
+    point-to-point sends (every rank sends its eighth to the six others over its own links): both phases move an
+    eighth of the panel per link, 2 x panel_bytes / 8 per step instead of panel_bytes.  Same bytes land in the same
+    receive buffer; chosen with CK_PANEL_EXCHANGE=p2p (bench.py) until it has been timed on an 8-GPU node."""
+
+    def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True,
+                 exchange: str = "broadcast"):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
         self.lookahead = bool(lookahead)
+        if exchange not in ("broadcast", "p2p"):
+            raise ValueError("exchange must be 'broadcast' or 'p2p'")
+        self.exchange = exchange
         self.arena = None
         # this rank's breakdown of the last predict(): panel_ms (panel steps it owned, incl. the look-ahead column
         # update in front of them), update_ms (trailing + right-hand-side updates, collective enqueue), bcast_wait_ms
@@ -105,6 +126,60 @@ class DistributedJoint:
         assert 0 <= off and off + nbytes <= self.arena.numel(), "panel outside the arena"
         return self.arena[off:off + nbytes].view(torch.float64)
 
+    def _pieces(self, n):
+        """[lo, hi) of the world pieces of an n-element panel (multiples of 512 elements, the last takes the rest)."""
+        step = -(-(-(-n // self.world)) // 512) * 512
+        return [(min(r * step, n), min((r + 1) * step, n)) for r in range(self.world)]
+
+    def _stream_ordered(self):
+        try:
+            return self.dist.get_backend(self.group) == "nccl"
+        except Exception:
+            return False
+
+    def _exchange(self, K, src, async_op=False):
+        """Panel K from its owner `src` into every rank's buffer for it."""
+        t = self._panel_tensor(K)
+        dist = self.dist
+        if self.exchange == "broadcast" or self.world < 3 or not hasattr(dist, "P2POp"):
+            return dist.broadcast(t, src=src, group=self.group, async_op=async_op)
+        pc = self._pieces(t.numel())
+        me = self.rank
+        ops1, ops2 = [], []
+        if me == src:                                   # phase 1: scatter, piece r -> rank r
+            for r in range(self.world):
+                if r != src and pc[r][1] > pc[r][0]:
+                    ops1.append(dist.P2POp(dist.isend, t[pc[r][0]:pc[r][1]], r, self.group))
+            lo, hi = pc[src]                            # the owner's own piece goes to everybody in phase 2
+            for r in range(self.world):
+                if r != src and hi > lo:
+                    ops2.append(dist.P2POp(dist.isend, t[lo:hi], r, self.group))
+        else:
+            lo, hi = pc[me]
+            if hi > lo:
+                ops1.append(dist.P2POp(dist.irecv, t[lo:hi], src, self.group))
+            for r in range(self.world):                 # phase 2: all-gather of the pieces by point-to-point sends
+                if r == me:
+                    continue
+                if r != src and hi > lo:
+                    ops2.append(dist.P2POp(dist.isend, t[lo:hi], r, self.group))
+                if pc[r][1] > pc[r][0]:
+                    ops2.append(dist.P2POp(dist.irecv, t[pc[r][0]:pc[r][1]], r, self.group))
+        works = []
+        if ops1:
+            works += dist.batch_isend_irecv(ops1)
+        if me != src and works and not self._stream_ordered():
+            for w in works:                             # my piece must have arrived before I pass it on (RCCL: both
+                w.wait()                                # batches run in order on the communicator's stream)
+            works = []
+        if ops2:
+            works += dist.batch_isend_irecv(ops2)
+        w = _Works(works)
+        if async_op:
+            return w
+        w.wait()
+        return None
+
     def _sweep_lookahead(self, nK):
         """Factor / broadcast / apply with the next panel's factorisation and transfer under the
         current panel's update.  The collective is enqueued BEFORE the big update kernels, so its
@@ -116,7 +191,7 @@ class DistributedJoint:
         if self.rank == 0:
             h.panel_factor(0)
         t1 = mk()
-        dist.broadcast(self._panel_tensor(0), src=0, group=self.group)
+        self._exchange(0, 0)
         self._steps.append((t0, t1, t1, mk()))
         for K in range(nK):
             nxt, work = K + 1, None
@@ -126,7 +201,7 @@ class DistributedJoint:
                     h.panel_apply_sigma(K, nxt, nxt)
                     h.panel_factor(nxt)
                 t1 = mk()
-                work = dist.broadcast(self._panel_tensor(nxt), src=nxt % self.world, group=self.group, async_op=True)
+                work = self._exchange(nxt, nxt % self.world, async_op=True)
             else:
                 t1 = t0
             h.panel_apply_sigma(K, nxt + 1, nK - 1)
@@ -163,7 +238,7 @@ class DistributedJoint:
                     h.panel_factor(K)
                 t1 = mk()
                 if self.world > 1:
-                    dist.broadcast(self._panel_tensor(K), src=owner, group=self.group)
+                    self._exchange(K, owner)
                 t2 = mk()
                 h.panel_apply(K, native.APPLY_SIGMA | native.APPLY_AUX)
                 t3 = mk()

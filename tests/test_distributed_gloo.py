@@ -31,10 +31,11 @@ def _worker(rank, world, port, case, q):
     try:
         from sif_xco2_cokriging_amd.distributed import DistributedJoint
         from tests.fake_panel_handle import FakePanelHandle
-        if case in ("solve", "solve_sequential"):
+        if case in ("solve", "solve_sequential", "solve_p2p", "solve_p2p_sequential"):
             g = load_golden("joint_solve")
             h = FakePanelHandle(g["params_A"], [g["coords0_A"], g["coords1_A"]], [g["values0_A"], g["values1_A"]], 0)
-            r = DistributedJoint(h, rank, world, dist_module=dist, lookahead=(case == "solve")).prepare(len(g["pcoords_A"]))
+            r = DistributedJoint(h, rank, world, dist_module=dist, lookahead=case in ("solve", "solve_p2p"),
+                                 exchange="p2p" if "p2p" in case else "broadcast").prepare(len(g["pcoords_A"]))
             pred, err = r.predict(1, g["pcoords_A"])
             q.put((rank, "ok", pred, err))
         elif case == "vario":
@@ -82,10 +83,12 @@ def _run(world, case):
     return sorted(out, key=lambda t: t[0])
 
 
-@pytest.mark.parametrize("world,case", [(2, "solve"), (3, "solve"), (2, "solve_sequential")])
+@pytest.mark.parametrize("world,case", [(2, "solve"), (3, "solve"), (2, "solve_sequential"), (3, "solve_p2p"),
+                                        (4, "solve_p2p"), (3, "solve_p2p_sequential")])
 def test_joint_predict_two_ranks(world, case):
     """look-ahead schedule (asynchronous broadcast of panel K + 1 under the update by panel K) and the
-    plain factor -> broadcast -> apply sequence"""
+    plain factor -> broadcast -> apply sequence; the panel exchange as one broadcast or as scatter + point-to-point
+    all-gather (exchange="p2p": every rank forwards its piece to all the others)"""
     g = load_golden("joint_solve")
     out = _run(world, case)
     for rank, status, pred, err in out:
