@@ -143,14 +143,14 @@ struct ck_handle {
                                                       // (the pairs the kernels leave to the host are decided on these)
     double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
     unsigned long long* vg_best = nullptr;       // extreme-pair hints of the extent pass (ck_vario.hip)
-    double *vg_ib = nullptr, *vg_jb = nullptr;   // bounding balls: 256-point "i" blocks, 1024-point "j" chunks
-    double *vg_ib64 = nullptr, *vg_jb256 = nullptr;   // ... and of the binning pass's wave tiles / sub-chunks
+    double *vg_jb = nullptr, *vg_ib64 = nullptr, *vg_jb256 = nullptr;   // bounding balls: 1024-point "j" chunks, 64-point
+                                                                        // "i" blocks (wave tiles), 256-point sub-chunks
     int64_t vg_ni = 0, vg_nj = 0;
-    int vg_same = 0, vg_grid = 0, vg_bgrid = 0;
+    int vg_same = 0, vg_bgrid = 0;
     void* vg_part = nullptr;
     double* vg_psum = nullptr;
     unsigned long long* vg_pcnt = nullptr;
-    double* vg_out = nullptr;          // thi[38] | dthr[38] | sums[36] | counts[37] (8-byte words)
+    double* vg_out = nullptr;          // xa[38] | xb[38] | dthr[38] | sums[36] | counts[37] (8-byte words) | kernel arguments
     CkVarioPair* vg_list = nullptr;    // pairs left to the host
     unsigned* vg_count = nullptr;
     unsigned vg_list_cap = 0;
@@ -1663,12 +1663,12 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {
     void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
-                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_ib, h->vg_jb, h->vg_ib64, h->vg_jb256,
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_jb, h->vg_ib64, h->vg_jb256,
                   h->vg_best, h->vg_list, h->vg_count};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
-    h->vg_ib = h->vg_jb = h->vg_ib64 = h->vg_jb256 = nullptr;
+    h->vg_jb = h->vg_ib64 = h->vg_jb256 = nullptr;
     h->vg_best = nullptr;
     h->vg_part = nullptr;
     h->vg_psum = nullptr;
@@ -1782,22 +1782,19 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
         h->vg_nj = n_j;
         if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv, h->vg_cj, h->vg_vj)) return -1;
     }
-    HIPCHK(hipMalloc((void**)&h->vg_ib, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 256) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_ib64, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 64) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1024) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_jb256, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 256) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_best, 16));
-    ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 256, h->vg_ib);
     ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 64, h->vg_ib64);
     ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1024, h->vg_jb);
     ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 256, h->vg_jb256);
     HIPCHK(hipGetLastError());
-    h->vg_grid = ck_vario_grid(h->vg_ni, h->vg_nj);
     h->vg_bgrid = ck_vario_bin_grid(h->vg_ni, h->vg_nj);
-    HIPCHK(hipMalloc(&h->vg_part, h->vg_grid * sizeof(CkVarioExt)));
+    HIPCHK(hipMalloc(&h->vg_part, h->vg_bgrid * sizeof(CkVarioExt)));
     HIPCHK(hipMalloc((void**)&h->vg_psum, (size_t)h->vg_bgrid * CK_VG_MAXBINS * 8));
     HIPCHK(hipMalloc((void**)&h->vg_pcnt, (size_t)h->vg_bgrid * (CK_VG_MAXBINS + 1) * 8));
-    HIPCHK(hipMalloc((void**)&h->vg_out, (2 * (CK_VG_MAXBINS + 2) + CK_VG_MAXBINS + CK_VG_MAXBINS + 1) * 8));
+    HIPCHK(hipMalloc((void**)&h->vg_out, (3 * (CK_VG_MAXBINS + 2) + CK_VG_MAXBINS + CK_VG_MAXBINS + 1) * 8 + CK_VG_ARGS_BYTES));
     HIPCHK(hipMalloc((void**)&h->vg_count, sizeof(unsigned)));
     h->vg_list_cap = 1u << 20;
     HIPCHK(hipMalloc((void**)&h->vg_list, (size_t)h->vg_list_cap * sizeof(CkVarioPair)));
@@ -1854,14 +1851,14 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     // Round 0 normally settles both extremes.  Further rounds only when every pair within the band of the largest
     // q <= cap turns out to lie beyond max_dist: the cap then moves below them.
     for (int round = 0; round < 64 && !have_hi; ++round) {
-        ck_launch_vario_extent(h->stream, h->vg_grid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
-                               h->rank, h->world, h->vg_ib, h->vg_jb, vario_cmax(cap), h->vg_best);
+        ck_launch_vario_extent(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
+                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jb256, vario_cmax(cap), h->vg_best);
         HIPCHK(hipGetLastError());
-        std::vector<CkVarioExt> part(h->vg_grid);
-        HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_grid * sizeof(CkVarioExt), hipMemcpyDeviceToHost, h->stream));
+        std::vector<CkVarioExt> part(h->vg_bgrid);
+        HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_bgrid * sizeof(CkVarioExt), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         CkVarioExt best = part[0];
-        for (int g = 1; g < h->vg_grid; ++g) {
+        for (int g = 1; g < h->vg_bgrid; ++g) {
             if (part[g].rmin < best.rmin) {
                 best.rmin = part[g].rmin;
                 best.imin = part[g].imin;
@@ -1878,8 +1875,9 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
         std::vector<CkVarioPair> cand;
         for (int pass = 0; pass < 3; ++pass) {
             HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
-            ck_launch_vario_collect(h->stream, h->vg_grid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, qtop_lo, cap,
-                                    qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib, h->vg_jb);
+            ck_launch_vario_collect(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, qtop_lo, cap,
+                                    qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib64, h->vg_jb,
+                                    h->vg_jb256);
             HIPCHK(hipGetLastError());
             bool overflow = false;
             if (vario_fetch_list(h, cand, &overflow)) return -1;
@@ -1938,35 +1936,48 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     // levels it passes (d > threshold: pd.cut's right-closed intervals, src/fields.py:214-216); a pair that passes
     // level E is not retained (d > max_dist, :212, or beyond the last edge, where pd.cut yields no bin).
     const double dcap = fmin(max_dist, edges[nb]);
-    double dthr[CK_VG_MAXBINS + 2], thi[CK_VG_MAXBINS + 2], tq[CK_VG_MAXBINS + 2];
+    double dthr[CK_VG_MAXBINS + 2], xa[CK_VG_MAXBINS + 2], xb[CK_VG_MAXBINS + 2], tq[CK_VG_MAXBINS + 2];
     int E = 0;
     for (int e = 1; e < nb && edges[e] < dcap; ++e) dthr[++E] = edges[e];
     dthr[++E] = dcap;
-    dthr[0] = thi[0] = tq[0] = 0.0;
-    double beta = 0.0;
+    dthr[0] = xa[0] = xb[0] = tq[0] = 0.0;
+    double q_reach = 0.0;   // largest q that can still be inside the cap's band
     for (int e = 1; e <= E; ++e) {
         tq[e] = vario_q_of_dist(metric, dthr[e]);
-        const double bnd = vario_band(metric, tq[e]);
-        thi[e] = tq[e] + bnd;
         if (!(tq[e] > 0.0)) return fail("variogram bin edge too close to zero");
-        beta = fmax(beta, bnd / tq[e]);
-        if (e > 1 && !(tq[e] - bnd > thi[e - 1])) return fail("variogram bin edges closer than the rounding band of the distances");
+        // the binning kernel's monotone x (ck_vario.hip): Euclid x = q; haversine x = q / 2 - 1 from a dot product,
+        // which costs an absolute 1e-15 of q near x = -1 on top of the band of the difference form
+        const double bnd = vario_band(metric, tq[e]) + (metric == CK_METRIC_HAVERSINE ? 3e-15 : 0.0);
+        const double qa = tq[e] + bnd, qb = tq[e] - bnd;
+        if (metric == CK_METRIC_HAVERSINE) {
+            xa[e] = (double)(0.5L * (long double)qa - 1.0L);
+            xb[e] = (double)(0.5L * (long double)qb - 1.0L);
+        } else {
+            xa[e] = qa;
+            xb[e] = qb;
+        }
+        if (!(xb[e] < xa[e])) return fail("variogram bin edge below the resolution of the distances");
+        if (e > 1 && !(xb[e] > xa[e - 1])) return fail("variogram bin edges closer than the rounding band of the distances");
+        q_reach = qa;
     }
-    const double gam = 1.0 + 2.5 * beta;
-    double* d_thi = h->vg_out;
-    double* d_dthr = h->vg_out + CK_VG_MAXBINS + 2;
-    double* d_sums = h->vg_out + 2 * (CK_VG_MAXBINS + 2);
+    double* d_xa = h->vg_out;
+    double* d_xb = h->vg_out + (CK_VG_MAXBINS + 2);
+    double* d_dthr = h->vg_out + 2 * (CK_VG_MAXBINS + 2);
+    double* d_sums = h->vg_out + 3 * (CK_VG_MAXBINS + 2);
     long long* d_cnt = (long long*)(d_sums + CK_VG_MAXBINS);
-    HIPCHK(hipMemcpyAsync(d_thi, thi, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    void* d_args = (void*)(d_cnt + CK_VG_MAXBINS + 1);
+    HIPCHK(hipMemcpyAsync(d_xa, xa, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_xb, xb, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d_dthr, dthr, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // xa / xb / dthr are stack arrays
     std::vector<CkVarioPair> fix;
     for (int pass = 0; pass < 3; ++pass) {
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         ck_launch_vario_bin(h->stream, metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv, h->vg_ni, h->vg_ju,
-                            h->vg_jv, h->vg_nj, E, d_thi, d_dthr, gam, vario_cmax(thi[E]), h->vg_ib64, h->vg_jb, h->vg_jb256,
+                            h->vg_jv, h->vg_nj, E, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jb256,
                             h->vg_bgrid, h->vg_psum, h->vg_pcnt, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world,
-                            nb, d_sums, d_cnt);
+                            nb, d_sums, d_cnt, d_args);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         bool overflow = false;

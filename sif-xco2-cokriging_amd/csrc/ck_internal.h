@@ -122,24 +122,28 @@ struct CkVarioPair {
 };
 void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int metric, double* u0, double* u1,
                           double* u2);
-int ck_vario_grid(int64_t ni, int64_t nj);
-int ck_vario_bin_grid(int64_t ni, int64_t nj);
-// iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]; q = squared chord | squared distance
+int ck_vario_bin_grid(int64_t ni, int64_t nj);   // workgroups of the three pair passes (wave tiles of 64 x 1024 points)
+// iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]; q = squared chord | squared distance;
+// ib64 / jb1024 / jb256: bounding balls of the 64-point "i" blocks, 1024-point "j" chunks and 256-point sub-chunks
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
-                            int64_t nj, double qcap, void* part, int rank, int world, const double* ib, const double* jb,
-                            double cmax, unsigned long long* best /* 2 words */);
+                            int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
+                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best /* 2 words */);
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                              int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
-                             unsigned cap, int rank, int world, const double* ib, const double* jb);
+                             unsigned cap, int rank, int world, const double* ib64, const double* jb1024,
+                             const double* jb256);
 // tile culling (ck_vario.hip): bounding balls of blocks of `blk` consecutive points, 4 x nblk doubles
 int64_t ck_vario_nblocks(int64_t n, int blk);
 void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, double* out);
-// levels 1 .. nlev (thi / dthr indexed by level); counts: CK_VG_MAXBINS + 1 words, the last = pairs visited
+// levels 1 .. nlev (xa / xb / dthr indexed by level; x = q (Euclid) or q / 2 - 1 (haversine), see ck_vario.hip);
+// counts: CK_VG_MAXBINS + 1 words, the last = pairs visited; args_dev: CK_VG_ARGS_BYTES of device memory
+#define CK_VG_ARGS_BYTES 256
 void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, const double* iu, const double* iv,
-                         int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* thi,
-                         const double* dthr, double gam, double cmax, const double* ib64, const double* jb1024,
+                         int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* xa,
+                         const double* xb, const double* dthr, double cmax, const double* ib64, const double* jb1024,
                          const double* jb256, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
-                         unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts);
+                         unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts,
+                         void* args_dev);
 
 // ---- local-neighbourhood cokriging (ck_local.hip) -------------------------------------------
 // pc: 3 x mpad prediction-site coordinates, sc: 3 x npad site coordinates (exact-formula form)

@@ -28,13 +28,14 @@
 // registers) x 1024 "j" points (the same for every lane: scalar loads); per 256-point sub-chunk the bounding
 // balls of the two point blocks say which levels every pair passes (nlow) and which none can reach (> nhigh),
 // so a pair is compared against nhigh - nlow thresholds only -- with the points in Hilbert order 1 to 3.  A lane
-// keeps CUMULATIVE sums S[k] = sum of the cloud values of its pairs that pass level nlow + k (and counts
-// C[k]) in registers: nested compares, one FMA and one integer add per level passed; bin nlow + k is
-// S[k] - S[k+1].  They are reduced over the wave and added to the wave's histogram in LDS only when nlow
-// changes.  No LDS traffic and no atomics in the pair loop, ~60 VGPRs: eight waves per SIMD (the first version
+// keeps one sum and one count per bin of the window in registers (slot k = bin nlow + k): nested compares on the
+// way up, one FMA and one integer add where the pair stops.  They are reduced over the wave and added to the wave's
+// histogram in LDS only when nlow changes.  No LDS traffic and no atomics in the pair loop (the first version
 // kept per-lane histograms in LDS -- 113 KB, one wave per SIMD, two LDS atomics per pair).
 // Sums are deterministic: fixed tile -> wave assignment, fixed reduction orders.
 #include "ck_internal.h"
+
+#include <utility>
 
 #define VG_TPB 256
 #define VG_JCHUNK 1024   // "j" points of a pair tile
@@ -141,75 +142,104 @@ __device__ __forceinline__ void tile_q_range(P ib, long nI, long bi, P jb, long 
     *qhi = hi1 * hi1 * (1.0 + 1e-12);
 }
 
+// Read-only data at wave-uniform addresses ("j" points, thresholds, bounding balls) is read through the CONSTANT
+// address space: hipcc then fetches it with scalar loads into SGPRs whatever stores and atomics the kernel also
+// contains (with plain global pointers -- even const __restrict__ kernel parameters -- the list append's atomic in the
+// same loop made it fall back to per-lane vector loads of one and the same address).  Nothing writes these arrays
+// while the kernels run.
+typedef const double __attribute__((address_space(4))) * vg_cptr;
+__device__ __forceinline__ vg_cptr vg_const(const double* p) { return (vg_cptr)(uintptr_t)p; }
+
 // ---- pass 1a: extreme pairs in q-space --------------------------------------------------------------
 // Largest q <= qcap and smallest positive q over this process's pair tiles (qcap already carries the upper
-// band of max_dist: the host decides the pairs near it).
-__global__ __launch_bounds__(VG_TPB) void k_vario_extent(int same, const double* __restrict__ iu0,
-                                                          const double* __restrict__ iu1,
-                                                          const double* __restrict__ iu2, long ni,
-                                                          const double* __restrict__ ju0,
-                                                          const double* __restrict__ ju1,
-                                                          const double* __restrict__ ju2, long nj, double qcap,
-                                                          VarioPartialExt* __restrict__ part, int rank, int world,
-                                                          const double* __restrict__ ib, const double* __restrict__ jb,
-                                                          double cmax, unsigned long long* best) {
-    // best[0]: bit pattern of the largest retained q any workgroup has seen so far, best[1]: of the smallest
-    // positive one (non-negative doubles order like their bit patterns).  A tile whose bounding balls say that all
-    // its pairs lie strictly inside (qlo, qhi) with qhi < best[0] and qlo > best[1] cannot change either extreme
-    // and is skipped; a stale hint only makes the test more conservative.  Nine tiles in ten go this way once the
-    // first wave of workgroups has reported: the largest retained lag sits in the tiles that straddle max_dist,
-    // the smallest positive one in tiles whose balls touch.
+// band of max_dist: the host decides the pairs near it).  Same tiling as the binning pass: a wave owns 64 "i"
+// points x 1024 "j" points and decides per 256-point sub-chunk whether it can hold a new extreme.
+struct VarioExtArgs {
+    int same, rank, world;
+    const double *iu0, *iu1, *iu2;
+    long ni;
+    const double *ju0, *ju1, *ju2;
+    long nj;
+    const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 256-point sub-chunks
+    double qcap, cmax;
+};
+
+__global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, VarioPartialExt* __restrict__ part,
+                                                          unsigned long long* best) {
+    // best[0]: bit pattern of the largest retained q any wave has seen so far, best[1]: of the smallest positive
+    // one (non-negative doubles order like their bit patterns).  A (sub-)tile whose bounding balls say that all its
+    // pairs lie strictly inside (qlo, qhi) with qhi < best[0] and qlo > best[1] cannot change either extreme and is
+    // skipped; a stale hint only makes the test more conservative.  Once the first waves have reported, what is left
+    // are the sub-tiles that straddle max_dist (largest retained lag) and those whose balls touch (smallest).
     __shared__ double red_r[VG_TPB];
     __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
-    const int tid = threadIdx.x;
-    const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const vg_cptr ju0 = vg_const(a.ju0), ju1 = vg_const(a.ju1), ju2 = vg_const(a.ju2);
+    const long ni = a.ni, nj = a.nj;
+    const long nIw = (ni + VG_IW - 1) / VG_IW, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK, nJs = (nj + VG_JSUB - 1) / VG_JSUB;
+    const long nwaves = (long)gridDim.x * (VG_TPB / 64), wid = (long)blockIdx.x * (VG_TPB / 64) + wv;
+    const double qcap = a.qcap;
     double rmin = 1e300, rmax = -1.0;
     long long imin = -1, jmin = -1, imax = -1, jmax = -1;
-    // tile list sharded over processes (ck_set_partition): this one takes the tiles t = rank (mod world)
-    for (long t = (long)blockIdx.x * world + rank; t < nI * nJ; t += (long)gridDim.x * world) {
+    for (long t = wid * a.world + a.rank; t < nIw * nJ; t += nwaves * a.world) {
         const long bi = t / nJ, bj = t - bi * nJ;
-        const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
-        if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
-        if (ib) {
+        const long i0 = bi * VG_IW, j0 = bj * VG_JCHUNK;
+        if (a.same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
+        {
             double dlo, qlo, qhi;
-            tile_q_range(ib, nI, bi, jb, nJ, bj, &dlo, &qlo, &qhi);
-            if (dlo > cmax) continue;   // no pair of this tile within max_dist
+            tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jb), nJ, bj, &dlo, &qlo, &qhi);
+            if (dlo > a.cmax) continue;   // no pair of this tile within max_dist
             qhi = fmin(qhi, qcap);
             const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
             const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
-            if (qhi < bmax && qlo > bmin) continue;   // cannot hold a new extreme (uniform: same loads for all lanes)
+            if (qhi < bmax && qlo > bmin) continue;
         }
-        const long i = i0 + tid;
+        const long i = i0 + lane;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
-        const double ax = iu0[ic], ay = iu1[ic], az = iu2[ic];
-        const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
-        const long kbeg = same ? (i + 1 - j0) : 0;        // per lane
-        long k0 = same ? (i0 + 1 - j0) : 0;               // uniform: the "j" point comes through scalar loads
-        if (k0 < 0) k0 = 0;
-#pragma unroll 8
-        for (long k = k0; k < jend; ++k) {
-            const double r = pair_q(ax, ay, az, ju0[j0 + k], ju1[j0 + k], ju2[j0 + k]);
-            if (live && k >= kbeg && r <= qcap) {
-                if (r > rmax) {
-                    rmax = r;
-                    imax = i;
-                    jmax = j0 + k;
-                }
-                if (r > 0.0 && r < rmin) {
-                    rmin = r;
-                    imin = i;
-                    jmin = j0 + k;
+        const double ax = a.iu0[ic], ay = a.iu1[ic], az = a.iu2[ic];
+        bool touched = false;
+        for (int sc = 0; sc < VG_JCHUNK / VG_JSUB; ++sc) {
+            const long js = j0 + (long)sc * VG_JSUB;
+            if (js >= nj) break;
+            if (a.same && js + VG_JSUB - 1 <= i0) continue;
+            {
+                double dlo, qlo, qhi;
+                tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jsb), nJs, js / VG_JSUB, &dlo, &qlo, &qhi);
+                if (dlo > a.cmax) continue;
+                qhi = fmin(qhi, qcap);
+                const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
+                const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
+                if (qhi < bmax && qlo > bmin) continue;
+            }
+            touched = true;
+            const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
+#pragma unroll 4
+            for (long k = 0; k < jlen; ++k) {
+                const long j = js + k;   // uniform: scalar loads
+                const double r = pair_q(ax, ay, az, ju0[j], ju1[j], ju2[j]);
+                if (live && (!a.same || j > i) && r <= qcap) {
+                    if (r > rmax) {
+                        rmax = r;
+                        imax = i;
+                        jmax = j;
+                    }
+                    if (r > 0.0 && r < rmin) {
+                        rmin = r;
+                        imin = i;
+                        jmin = j;
+                    }
                 }
             }
         }
-        if (ib) {   // publish this wave's extremes so far: hints for every workgroup's tile test above
+        if (touched) {   // publish this wave's extremes so far: hints for every wave's tests above
             double wmax = rmax, wmin = rmin;
             for (int off = 32; off > 0; off >>= 1) {
                 wmax = fmax(wmax, __shfl_xor(wmax, off));
                 wmin = fmin(wmin, __shfl_xor(wmin, off));
             }
-            if ((tid & 63) == 0) {
+            if (lane == 0) {
                 if (wmax > 0.0) atomicMax(&best[0], (unsigned long long)__double_as_longlong(wmax));
                 if (wmin < 1e300) atomicMin(&best[1], (unsigned long long)__double_as_longlong(wmin));
             }
@@ -256,56 +286,70 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(int same, const double*
 
 // ---- pass 1b: every pair within the band of the two extremes -> list (the host decides them) ---------
 // top candidates: qtop_lo <= q <= qcap; bottom candidates: 0 < q <= qbot_hi
-__global__ __launch_bounds__(VG_TPB) void k_vario_collect(int same, const double* __restrict__ iu0,
-                                                           const double* __restrict__ iu1,
-                                                           const double* __restrict__ iu2, long ni,
-                                                           const double* __restrict__ ju0,
-                                                           const double* __restrict__ ju1,
-                                                           const double* __restrict__ ju2, long nj, double qtop_lo,
-                                                           double qcap, double qbot_hi, CkVarioPair* __restrict__ list,
-                                                           unsigned* __restrict__ count, unsigned cap, int rank, int world,
-                                                           const double* __restrict__ ib, const double* __restrict__ jb) {
-    const int tid = threadIdx.x;
-    const long nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
-    for (long t = (long)blockIdx.x * world + rank; t < nI * nJ; t += (long)gridDim.x * world) {
+__global__ __launch_bounds__(VG_TPB) void k_vario_collect(const VarioExtArgs a, double qtop_lo, double qbot_hi,
+                                                           CkVarioPair* __restrict__ list, unsigned* __restrict__ count,
+                                                           unsigned cap) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const vg_cptr ju0 = vg_const(a.ju0), ju1 = vg_const(a.ju1), ju2 = vg_const(a.ju2);
+    const long ni = a.ni, nj = a.nj;
+    const long nIw = (ni + VG_IW - 1) / VG_IW, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK, nJs = (nj + VG_JSUB - 1) / VG_JSUB;
+    const long nwaves = (long)gridDim.x * (VG_TPB / 64), wid = (long)blockIdx.x * (VG_TPB / 64) + wv;
+    const double qcap = a.qcap;
+    for (long t = wid * a.world + a.rank; t < nIw * nJ; t += nwaves * a.world) {
         const long bi = t / nJ, bj = t - bi * nJ;
-        const long i0 = bi * VG_TPB, j0 = bj * VG_JCHUNK;
-        if (same && j0 + VG_JCHUNK - 1 <= i0) continue;
-        if (ib) {
+        const long i0 = bi * VG_IW, j0 = bj * VG_JCHUNK;
+        if (a.same && j0 + VG_JCHUNK - 1 <= i0) continue;
+        {
             double dlo, qlo, qhi;
-            tile_q_range(ib, nI, bi, jb, nJ, bj, &dlo, &qlo, &qhi);
+            tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jb), nJ, bj, &dlo, &qlo, &qhi);
             if (!((qhi >= qtop_lo && qlo <= qcap) || qlo <= qbot_hi)) continue;
         }
-        const long i = i0 + tid;
+        const long i = i0 + lane;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
-        const double ax = iu0[ic], ay = iu1[ic], az = iu2[ic];
-        const long jend = (nj - j0 < VG_JCHUNK) ? (nj - j0) : VG_JCHUNK;
-        const long kbeg = same ? (i + 1 - j0) : 0;
-        long k0 = same ? (i0 + 1 - j0) : 0;
-        if (k0 < 0) k0 = 0;
+        const double ax = a.iu0[ic], ay = a.iu1[ic], az = a.iu2[ic];
+        for (int sc = 0; sc < VG_JCHUNK / VG_JSUB; ++sc) {
+            const long js = j0 + (long)sc * VG_JSUB;
+            if (js >= nj) break;
+            if (a.same && js + VG_JSUB - 1 <= i0) continue;
+            {
+                double dlo, qlo, qhi;
+                tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jsb), nJs, js / VG_JSUB, &dlo, &qlo, &qhi);
+                if (!((qhi >= qtop_lo && qlo <= qcap) || qlo <= qbot_hi)) continue;
+            }
+            const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
 #pragma unroll 4
-        for (long k = k0; k < jend; ++k) {
-            const double q = pair_q(ax, ay, az, ju0[j0 + k], ju1[j0 + k], ju2[j0 + k]);
-            const bool hit = (q >= qtop_lo && q <= qcap) || (q > 0.0 && q <= qbot_hi);
-            if (live && k >= kbeg && hit) {
-                const unsigned at = atomicAdd(count, 1u);
-                if (at < cap) list[at] = CkVarioPair{(int)i, (int)(j0 + k), 0, 0};
+            for (long k = 0; k < jlen; ++k) {
+                const long j = js + k;
+                const double q = pair_q(ax, ay, az, ju0[j], ju1[j], ju2[j]);
+                const bool hit = (q >= qtop_lo && q <= qcap) || (q > 0.0 && q <= qbot_hi);
+                if (live && (!a.same || j > i) && hit) {
+                    const unsigned at = atomicAdd(count, 1u);
+                    if (at < cap) list[at] = CkVarioPair{(int)i, (int)j, 0, 0};
+                }
             }
         }
     }
 }
 
 // ---- pass 2: binning ---------------------------------------------------------------------------------
+// The kernel compares a monotone function x of q whose thresholds the host provides as two arrays per level:
+// A[e] (x > A[e]: level passed for certain) and B[e] < A[e] (x <= B[e]: certainly not passed; in between: the pair is
+// inside the level's rounding band and is decided exactly).
+//   Euclidean  x = q = dx^2 + dy^2                                   (4 FP64 operations per pair);
+//   haversine  x = -(u_i . u_j) = q / 2 - 1   with -u_i kept in the lane (3 operations per pair instead of the 6 of
+//              |u_i - u_j|^2; the cancellation near x = -1 costs an ABSOLUTE 1e-15 of accuracy in q, which the band
+//              of this pass allows for -- ck_api.hip: vario_band_bin).
 struct VarioBinArgs {
     int same, nlev, rank, world;
     const double *iu0, *iu1, *iu2, *iv;
     long ni;
     const double *ju0, *ju1, *ju2, *jv;
     long nj;
-    const double* thi;    // [1 .. nlev]: q-space threshold + band (level passed for certain if q > thi)
+    const double* xa;     // [1 .. nlev]: x > xa[e]: level e passed for certain
+    const double* xb;     // [1 .. nlev]: x <= xb[e]: certainly not
     const double* dthr;   // [1 .. nlev]: the threshold as a distance (edge or cap), for the exact decision
-    double gam;           // q * gam > thi  <=>  q within the band or above
     double cmax;          // largest chord that can reach the band of the cap
     const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 256-point sub-chunks
     double* part_sum;
@@ -314,62 +358,73 @@ struct VarioBinArgs {
     unsigned* count;
     unsigned cap;
 };
+typedef const VarioBinArgs __attribute__((address_space(4))) * vg_args_ptr;
 
 struct VarioPairCtx {
-    double ax, ay, bx, by;
+    double ax, ay, bx, by;   // Euclidean: the raw coordinates
     long i, j;
 };
 
 // Is the pair (within the band of level `lev`) above the threshold?  Euclidean: decided here, exactly as the
 // reference would; haversine: deferred to the host, here "not above".
 template <int METRIC>
-__device__ __forceinline__ bool vario_near(const VarioBinArgs& a, const VarioPairCtx& c, int lev) {
-    if (METRIC == CK_METRIC_EUCLID) return euclid_exact(c.ax, c.ay, c.bx, c.by) > a.dthr[lev];
-    const unsigned at = atomicAdd(a.count, 1u);
-    if (at < a.cap) a.list[at] = CkVarioPair{(int)c.i, (int)c.j, lev, 0};
+__device__ __forceinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c, int lev) {
+    if (METRIC == CK_METRIC_EUCLID) return euclid_exact(c.ax, c.ay, c.bx, c.by) > vg_const(a->dthr)[lev];
+    const unsigned at = atomicAdd(a->count, 1u);
+    if (at < a->cap) a->list[at] = CkVarioPair{(int)c.i, (int)c.j, lev, 0};
     return false;
 }
 
-// levels e0 + K .. e0 + NW for one pair: cumulative accumulators of the levels it passes
+// Levels e0 + K .. e0 + NW for one pair.  Slot k accumulates the pairs of bin e0 + k, i.e. those that pass level
+// e0 + k and not level e0 + k + 1: a lane only compares on its way up and accumulates once, where it stops (the
+// first version accumulated CUMULATIVE sums at every level passed and took differences afterwards -- one FMA and one
+// add more per level, and for smooth fields, whose near bins hold much smaller cloud values than the far ones, the
+// differences lost up to six digits).
+// slot K += the pair.  The empty asm with the slot number as an immediate keeps the nine update sites DISTINCT for the
+// optimiser: identical, it merges them into one block that indexes the accumulators with a run-time slot number,
+// and the accumulators then live in scratch memory (measured: 165 -> 399 ms).
+template <int K>
+__device__ __forceinline__ void vario_acc(double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], double m1, double m2) {
+    S[K] = fma(m1, m2, S[K]);
+    C[K] += 1u;
+    asm volatile("" : : "n"(K));   // last in its block: code is merged from the end of the blocks backwards
+}
+
 template <int METRIC, int K, int NW>
-__device__ __forceinline__ void vario_chain(const VarioBinArgs& a, const double (&T)[VG_SLOTS], double (&S)[VG_SLOTS],
-                                            unsigned (&C)[VG_SLOTS], double q, double m1, double m2, int e0,
-                                            const VarioPairCtx& c) {
+__device__ __forceinline__ void vario_chain(vg_args_ptr a, const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
+                                            double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], double x, double m1, double m2,
+                                            int e0, const VarioPairCtx& c) {
     if constexpr (K <= NW) {
-        if (q > T[K]) {
-            S[K] = fma(m1, m2, S[K]);
-            C[K] += 1u;
-            vario_chain<METRIC, K + 1, NW>(a, T, S, C, q, m1, m2, e0, c);
-        } else if (q * a.gam > T[K]) {
-            // slot 0 of a follow-up window is the previous window's last level: the pair was listed there already
-            if (!(K == 0 && METRIC == CK_METRIC_HAVERSINE) && vario_near<METRIC>(a, c, e0 + K)) {
-                S[K] = fma(m1, m2, S[K]);
-                C[K] += 1u;
-            }
+        if (x > A[K]) {
+            vario_chain<METRIC, K + 1, NW>(a, A, B, S, C, x, m1, m2, e0, c);
+        } else {
+            // inside the band of level e0 + K: decided exactly (a pair that is above it cannot reach the next level).
+            // Slot 0 of a follow-up window is the previous window's last level: haversine pairs were listed there.
+            bool up = false;
+            if (x > B[K]) up = (K == 0 && METRIC == CK_METRIC_HAVERSINE) ? false : vario_near<METRIC>(a, c, e0 + K);
+            if (up)
+                vario_acc<K>(S, C, m1, m2);
+            else if (K > 0)   // K == 0: the pair belongs to the window below
+                vario_acc<(K > 0 ? K - 1 : 0)>(S, C, m1, m2);
         }
+    } else {
+        vario_acc<NW>(S, C, m1, m2);   // passed every level of the window
     }
 }
 
-// one 256-point sub-chunk against the wave's 64 "i" points.  BASE: slot 0 is passed by every pair (no compare).
+// BASE: level e0 is passed by every pair of the sub-chunk (no compare).
 // NW: number of compared slots (window width).  CHECK: per-pair validity (ragged last block, diagonal).
-// Read-only data at wave-uniform addresses ("j" points, thresholds, bounding balls) is read through the CONSTANT
-// address space: hipcc then fetches it with scalar loads into SGPRs whatever stores and atomics the kernel also
-// contains (with plain global pointers -- even const __restrict__ kernel parameters -- the list append's atomic in the
-// same loop made it fall back to per-lane vector loads of one and the same address).  Nothing writes these arrays
-// while the kernel runs.
-typedef const double __attribute__((address_space(4))) * vg_cptr;
-__device__ __forceinline__ vg_cptr vg_const(const double* p) { return (vg_cptr)(uintptr_t)p; }
-
 template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
-__device__ __forceinline__ void vario_pair(const VarioBinArgs& a, const double (&T)[VG_SLOTS], double (&S)[VG_SLOTS],
-                                           unsigned (&C)[VG_SLOTS], int e0, double ax, double ay, double az, double av,
-                                           long i, bool live, long j, double bx, double by, double bz, double bv) {
-    double q;
-    if (METRIC == CK_METRIC_HAVERSINE)
-        q = pair_q(ax, ay, az, bx, by, bz);
-    else {
+__device__ __forceinline__ void vario_pair(vg_args_ptr a, const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
+                                           double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], int e0, int same, double ax,
+                                           double ay, double az, double rx, double ry, double av, long i, bool live, long j,
+                                           double bx, double by, double bz, double bv) {
+    double x;
+    if (METRIC == CK_METRIC_HAVERSINE) {
+        x = fma(az, bz, fma(ay, by, ax * bx));   // (ax, ay, az) = -u_i
+    } else {
         const double dx = ax - bx, dy = ay - by;
-        q = dx * dx + dy * dy;
+        x = dx * dx + dy * dy;
     }
     double m1, m2;
     if (COV) {
@@ -378,27 +433,22 @@ __device__ __forceinline__ void vario_pair(const VarioBinArgs& a, const double (
     } else {
         m1 = m2 = av - bv;   // fields.py:384-385; the factor 0.5 is applied to the bin sums
     }
-    const VarioPairCtx c{ax, ay, bx, by, i, j};
-    if (!CHECK || (live && (!a.same || j > i))) {
-        if (BASE) {
-            S[0] = fma(m1, m2, S[0]);
-            C[0] += 1u;
-            vario_chain<METRIC, 1, NW>(a, T, S, C, q, m1, m2, e0, c);
-        } else {
-            vario_chain<METRIC, 0, NW>(a, T, S, C, q, m1, m2, e0, c);
-        }
-    }
+    const VarioPairCtx c{rx, ry, bx, by, i, j};
+    if (!CHECK || (live && (!same || j > i))) vario_chain<METRIC, BASE ? 1 : 0, NW>(a, A, B, S, C, x, m1, m2, e0, c);
 }
 
-// one 256-point sub-chunk against the wave's 64 "i" points.  BASE: slot 0 is passed by every pair (no compare).
-// NW: number of compared slots (window width).  CHECK: per-pair validity (ragged last block, diagonal).
+// one 256-point sub-chunk against the wave's 64 "i" points
 template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
-__device__ __forceinline__ void vario_subchunk(const VarioBinArgs& a, vg_cptr ju0, vg_cptr ju1, vg_cptr ju2, vg_cptr jv,
-                                               const double (&T)[VG_SLOTS], double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS],
-                                               int e0, double ax, double ay, double az, double av, long i, bool live,
+__device__ __forceinline__ void vario_subchunk(vg_args_ptr a, vg_cptr ju0, vg_cptr ju1, vg_cptr ju2, vg_cptr jv,
+                                               const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
+                                               double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], int e0, int same, double ax,
+                                               double ay, double az, double rx, double ry, double av, long i, bool live,
                                                long js, long jlen) {
     long k = 0;
-    for (; k + 4 <= jlen; k += 4) {   // four "j" points per round: their scalar loads merge (s_load_dwordx8 per array)
+    // Four "j" points per round: their scalar loads merge (s_load_dwordx8 per array).  (Fetching the next round's points
+    // a round ahead -- scalar loads return out of order, so a wave can only wait for all of them -- was measured and
+    // dropped: 32 more live SGPRs doubled the SGPR spills, 163 -> 199 ms.)
+    for (; k + 4 <= jlen; k += 4) {
         const long j = js + k;
         double bx[4], by[4], bz[4], bv[4];
 #pragma unroll
@@ -410,13 +460,27 @@ __device__ __forceinline__ void vario_subchunk(const VarioBinArgs& a, vg_cptr ju
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            vario_pair<METRIC, COV, NW, BASE, CHECK>(a, T, S, C, e0, ax, ay, az, av, i, live, j + u, bx[u], by[u], bz[u], bv[u]);
+            vario_pair<METRIC, COV, NW, BASE, CHECK>(a, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, live, j + u, bx[u],
+                                                     by[u], bz[u], bv[u]);
     }
     for (; k < jlen; ++k) {
         const long j = js + k;
-        vario_pair<METRIC, COV, NW, BASE, CHECK>(a, T, S, C, e0, ax, ay, az, av, i, live, j, ju0[j], ju1[j],
+        vario_pair<METRIC, COV, NW, BASE, CHECK>(a, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, live, j, ju0[j], ju1[j],
                                                  METRIC == CK_METRIC_HAVERSINE ? ju2[j] : 0.0, jv[j]);
     }
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the slot arrays are only ever indexed with
+// compile-time constants, so that they are split into registers before any loop is unrolled (a `for` loop over
+// them, even under #pragma unroll, kept them in scratch memory: by the time the loop was unrolled the optimiser had
+// merged the slots' identical update code into one block with a run-time index)
+template <class F, int... Is>
+__device__ __forceinline__ void vg_static_for(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void vg_for(F&& f) {
+    vg_static_for(f, std::make_integer_sequence<int, N>{});
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -429,81 +493,91 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+__device__ __forceinline__ double lane_value(double v, int src_lane) {   // wave-uniform src_lane: two v_readlane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
 
+// The arguments live in device memory and are read through the constant address space where they are needed
+// (scalar loads): as by-value kernel arguments their thirty pointers and sizes stayed in SGPRs for the whole kernel
+// and pushed the hot loop's thresholds and "j" points out into VGPR lanes (209 spilled SGPRs, 98 VGPRs).
 template <int METRIC, int COV>
-__global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs a) {
-    const vg_cptr ju0 = vg_const(a.ju0), ju1 = vg_const(a.ju1), ju2 = vg_const(a.ju2), jv = vg_const(a.jv);
-    const vg_cptr thi = vg_const(a.thi);
+__global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs* __restrict__ args) {
+    const vg_args_ptr a = (vg_args_ptr)(uintptr_t)args;
     __shared__ double hsum[VG_TPB / 64][VG_MAXBINS];
     __shared__ unsigned long long hcnt[VG_TPB / 64][VG_MAXBINS + 1];   // [VG_MAXBINS]: visited pairs
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (lane < VG_MAXBINS) hsum[wv][lane] = 0.0;
     if (lane <= VG_MAXBINS) hcnt[wv][lane] = 0ull;
-    const int E = a.nlev;
-    const double thi_lane = lane < E ? thi[lane + 1] : INFINITY;   // lane e - 1 holds the threshold of level e
-    const int thi_lo = __double2loint(thi_lane), thi_hi = __double2hiint(thi_lane);
-    const long ni = a.ni, nj = a.nj;
+    const int E = a->nlev, same = a->same;
+    // lane e - 1 holds the two thresholds of level e
+    const double xa_lane = lane < E ? vg_const(a->xa)[lane + 1] : INFINITY;
+    const double xb_lane = lane < E ? vg_const(a->xb)[lane + 1] : INFINITY;
+    const long ni = a->ni, nj = a->nj;
     const long nIw = (ni + VG_IW - 1) / VG_IW, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK, nJs = (nj + VG_JSUB - 1) / VG_JSUB;
     const long nwaves = (long)gridDim.x * (VG_TPB / 64), wid = (long)blockIdx.x * (VG_TPB / 64) + wv;
+    const int world = a->world, rank = a->rank;
+    const double cmax = a->cmax;
     double S[VG_SLOTS];
     unsigned C[VG_SLOTS];
-#pragma unroll
-    for (int k = 0; k < VG_SLOTS; ++k) {
-        S[k] = 0.0;
-        C[k] = 0u;
-    }
+    vg_for<VG_SLOTS>([&](auto k) {
+        S[k.value] = 0.0;
+        C[k.value] = 0u;
+    });
     int e0cur = -1;
     unsigned long long visited = 0;
-    // bins e0cur .. e0cur + 7 <- differences of the cumulative accumulators, summed over the wave
-    auto flush = [&]() {
+    // bins e0cur .. e0cur + 7 <- the slot accumulators, summed over the wave
+    // (always_inline: called from two places, and left as a call it would force the accumulators into scratch memory)
+    auto flush = [&]() __attribute__((always_inline)) {
         if (e0cur >= 0) {
-            double s[VG_SLOTS];
-            unsigned c[VG_SLOTS];
-#pragma unroll
-            for (int k = 0; k < VG_SLOTS; ++k) {
-                s[k] = wave_sum(S[k]);
-                c[k] = wave_sum_u(C[k]);
-                S[k] = 0.0;
-                C[k] = 0u;
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < VG_SLOTS - 1; ++k)
-                    if (e0cur + k < E) {
-                        hsum[wv][e0cur + k] += s[k] - s[k + 1];
-                        hcnt[wv][e0cur + k] += (unsigned long long)(c[k] - c[k + 1]);
-                    }
-            }
+            vg_for<VG_SLOTS - 1>([&](auto k) {   // slot 8 belongs to the follow-up window
+                const double sk = wave_sum(S[k.value]);
+                const unsigned ck = wave_sum_u(C[k.value]);
+                if (lane == 0 && e0cur + k.value < E) {
+                    hsum[wv][e0cur + k.value] += sk;
+                    hcnt[wv][e0cur + k.value] += (unsigned long long)ck;
+                }
+            });
+            vg_for<VG_SLOTS>([&](auto k) {
+                S[k.value] = 0.0;
+                C[k.value] = 0u;
+            });
         }
     };
     // wave tiles sharded over processes (ck_set_partition): this process takes the tiles t = rank (mod world)
-    for (long t = wid * a.world + a.rank; t < nIw * nJ; t += nwaves * a.world) {
+    for (long t = wid * world + rank; t < nIw * nJ; t += nwaves * world) {
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_IW, j0 = bj * VG_JCHUNK;
-        if (a.same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
+        if (same && j0 + VG_JCHUNK - 1 <= i0) continue;   // chunk entirely at or below the diagonal
         {
             double dlo, qlo, qhi;
-            tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jb), nJ, bj, &dlo, &qlo, &qhi);
-            if (dlo > a.cmax) continue;   // every pair beyond the cap
+            tile_q_range(vg_const(a->ib), nIw, bi, vg_const(a->jb), nJ, bj, &dlo, &qlo, &qhi);
+            if (dlo > cmax) continue;   // every pair beyond the cap
         }
         const long i = i0 + lane;
         const bool live = i < ni;
         const long ic = live ? i : ni - 1;
-        const double ax = a.iu0[ic], ay = a.iu1[ic], az = a.iu2[ic], av = a.iv[ic];
+        const double rx = a->iu0[ic], ry = a->iu1[ic], rz = a->iu2[ic], av = a->iv[ic];
+        // haversine: the lane keeps -u_i, so that x = (-u_i) . u_j grows with the distance
+        const double ax = METRIC == CK_METRIC_HAVERSINE ? -rx : rx, ay = METRIC == CK_METRIC_HAVERSINE ? -ry : ry, az = -rz;
+        const vg_cptr ju0 = vg_const(a->ju0), ju1 = vg_const(a->ju1), ju2 = vg_const(a->ju2), jv = vg_const(a->jv);
         for (int sc = 0; sc < VG_JCHUNK / VG_JSUB; ++sc) {
             const long js = j0 + (long)sc * VG_JSUB;
             if (js >= nj) break;
-            if (a.same && js + VG_JSUB - 1 <= i0) continue;
+            if (same && js + VG_JSUB - 1 <= i0) continue;
             const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
             double dlo, qlo, qhi;
-            tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jsb), nJs, js / VG_JSUB, &dlo, &qlo, &qhi);
-            if (dlo > a.cmax) continue;
+            tile_q_range(vg_const(a->ib), nIw, bi, vg_const(a->jsb), nJs, js / VG_JSUB, &dlo, &qlo, &qhi);
+            if (dlo > cmax) continue;
+            // the sub-chunk's x range (with the absolute slack of the dot-product form)
+            const double xlo = METRIC == CK_METRIC_HAVERSINE ? 0.5 * qlo - 1.0 - 2e-15 : qlo;
+            const double xhi = METRIC == CK_METRIC_HAVERSINE ? 0.5 * qhi - 1.0 + 2e-15 : qhi;
             // levels 1 .. nlow: passed by every pair; levels > nhigh: out of reach even with the band
-            const int nlow = __popcll(__ballot(thi_lane < qlo));
-            const int nhigh = __popcll(__ballot(thi_lane < qhi * a.gam));
+            const int nlow = __popcll(__ballot(xa_lane < xlo));
+            const int nhigh = __popcll(__ballot(xb_lane < xhi));
             if (nlow >= E) continue;   // every pair beyond the cap
-            const bool check = (i0 + VG_IW > ni) || (a.same && js < i0 + VG_IW);
+            const bool check = (i0 + VG_IW > ni) || (same && js < i0 + VG_IW);
             visited += (unsigned long long)jlen * VG_IW;
             for (int e0 = nlow;; e0 += VG_SLOTS - 1) {
                 if (e0 != e0cur) {
@@ -511,26 +585,27 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs a) {
                     e0cur = e0;
                 }
                 const int nw = (nhigh - e0 < VG_SLOTS - 1) ? (nhigh - e0) : (VG_SLOTS - 1);   // compared slots
-                double T[VG_SLOTS];
-                T[0] = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < VG_SLOTS; ++k) {
-                    const int lev = e0 + k;   // its threshold sits in lane lev - 1
+                double A[VG_SLOTS], B[VG_SLOTS];
+                vg_for<VG_SLOTS>([&](auto k) {
+                    const int lev = e0 + k.value;   // its thresholds sit in lane lev - 1
                     if (lev >= 1 && lev <= nhigh) {
-                        const int sl = lev - 1;
-                        T[k] = __hiloint2double(__builtin_amdgcn_readlane(thi_hi, sl), __builtin_amdgcn_readlane(thi_lo, sl));
-                    } else if (k > 0) {
-                        T[k] = INFINITY;
+                        A[k.value] = lane_value(xa_lane, lev - 1);
+                        B[k.value] = lane_value(xb_lane, lev - 1);
+                    } else {
+                        A[k.value] = B[k.value] = k.value > 0 ? INFINITY : -INFINITY;
                     }
-                }
+                });
                 const bool base = e0 == nlow;   // slot 0 = a level every pair passes (or the virtual level 0)
-#define VG_RUN(NWV)                                                                                                  \
-    if (check)                                                                                                       \
-        vario_subchunk<METRIC, COV, NWV, true, true>(a, ju0, ju1, ju2, jv, T, S, C, e0, ax, ay, az, av, i, live, js, jlen);             \
-    else                                                                                                             \
-        vario_subchunk<METRIC, COV, NWV, true, false>(a, ju0, ju1, ju2, jv, T, S, C, e0, ax, ay, az, av, i, live, js, jlen);
+#define VG_RUN(NWV)                                                                                                        \
+    if (check)                                                                                                             \
+        vario_subchunk<METRIC, COV, NWV, true, true>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, \
+                                                     live, js, jlen);                                                      \
+    else                                                                                                                   \
+        vario_subchunk<METRIC, COV, NWV, true, false>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay, az, rx, ry, av,   \
+                                                      i, live, js, jlen);
                 if (!base) {
-                    vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, T, S, C, e0, ax, ay, az, av, i, live, js, jlen);
+                    vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay,
+                                                                           az, rx, ry, av, i, live, js, jlen);
                 } else {
                     switch (nw) {
                     case 0: VG_RUN(0) break;
@@ -558,8 +633,8 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs a) {
             if (tid < VG_MAXBINS) s += hsum[w][tid];
             c += hcnt[w][tid];
         }
-        if (tid < VG_MAXBINS) a.part_sum[(long)blockIdx.x * VG_MAXBINS + tid] = s;
-        a.part_cnt[(long)blockIdx.x * (VG_MAXBINS + 1) + tid] = c;
+        if (tid < VG_MAXBINS) a->part_sum[(long)blockIdx.x * VG_MAXBINS + tid] = s;
+        a->part_cnt[(long)blockIdx.x * (VG_MAXBINS + 1) + tid] = c;
     }
 }
 
@@ -584,29 +659,46 @@ void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int me
     k_vario_prep<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(coords, n, metric, u0, u1, u2);
 }
 
-int ck_vario_grid(int64_t ni, int64_t nj) {
-    const int64_t nI = (ni + VG_TPB - 1) / VG_TPB, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
-    int64_t tiles = nI * nJ;
-    if (tiles < 1) tiles = 1;
-    return (int)(tiles < 2048 ? tiles : 2048);
+static VarioExtArgs vario_ext_args(int same, const double* iu, int64_t ni, const double* ju, int64_t nj, double qcap,
+                                   double cmax, int rank, int world, const double* ib64, const double* jb1024,
+                                   const double* jb256) {
+    VarioExtArgs a;
+    a.same = same;
+    a.rank = rank;
+    a.world = world;
+    a.iu0 = iu;
+    a.iu1 = iu + ni;
+    a.iu2 = iu + 2 * ni;
+    a.ni = ni;
+    a.ju0 = ju;
+    a.ju1 = ju + nj;
+    a.ju2 = ju + 2 * nj;
+    a.nj = nj;
+    a.ib = ib64;
+    a.jb = jb1024;
+    a.jsb = jb256;
+    a.qcap = qcap;
+    a.cmax = cmax;
+    return a;
 }
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
-                            int64_t nj, double qcap, void* part, int rank, int world, const double* ib, const double* jb,
-                            double cmax, unsigned long long* best) {
+                            int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
+                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best) {
     // best: two words of device memory, initialised here to "nothing seen yet" (largest retained q = 0.0, smallest
     // positive q = the largest finite double)
     static const unsigned long long init[2] = {0ULL, 0x7fefffffffffffffULL};
     (void)hipMemcpyAsync(best, init, sizeof(init), hipMemcpyHostToDevice, s);
-    k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj, ju + 2 * nj, nj,
-                                                       qcap, (VarioPartialExt*)part, rank, world, ib, jb, cmax, best);
+    k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
+        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part, best);
 }
 
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                              int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
-                             unsigned cap, int rank, int world, const double* ib, const double* jb) {
-    k_vario_collect<<<dim3(grid), dim3(VG_TPB), 0, s>>>(same, iu, iu + ni, iu + 2 * ni, ni, ju, ju + nj, ju + 2 * nj, nj,
-                                                        qtop_lo, qcap, qbot_hi, list, count, cap, rank, world, ib, jb);
+                             unsigned cap, int rank, int world, const double* ib64, const double* jb1024,
+                             const double* jb256) {
+    k_vario_collect<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
+        vario_ext_args(same, iu, ni, ju, nj, qcap, 0.0, rank, world, ib64, jb1024, jb256), qtop_lo, qbot_hi, list, count, cap);
 }
 
 // bounding balls of blocks of `blk` consecutive points: 4 x ceil(n / blk) doubles
@@ -618,10 +710,11 @@ void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, 
 }
 
 void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, const double* iu, const double* iv,
-                         int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* thi,
-                         const double* dthr, double gam, double cmax, const double* ib64, const double* jb1024,
+                         int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* xa,
+                         const double* xb, const double* dthr, double cmax, const double* ib64, const double* jb1024,
                          const double* jb256, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
-                         unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts) {
+                         unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts,
+                         void* args_dev) {
     VarioBinArgs a;
     a.same = same;
     a.nlev = nlev;
@@ -637,9 +730,9 @@ void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, c
     a.ju2 = ju + 2 * nj;
     a.jv = jv;
     a.nj = nj;
-    a.thi = thi;
+    a.xa = xa;
+    a.xb = xb;
     a.dthr = dthr;
-    a.gam = gam;
     a.cmax = cmax;
     a.ib = ib64;
     a.jb = jb1024;
@@ -649,17 +742,20 @@ void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, c
     a.list = list;
     a.count = count;
     a.cap = cap;
+    static_assert(sizeof(VarioBinArgs) <= CK_VG_ARGS_BYTES, "argument block");
+    (void)hipMemcpyAsync(args_dev, &a, sizeof(a), hipMemcpyHostToDevice, s);   // pageable source: staged before return
+    const VarioBinArgs* ad = (const VarioBinArgs*)args_dev;
     const dim3 g(grid), b(VG_TPB);
     if (metric == CK_METRIC_HAVERSINE) {
         if (covariogram)
-            k_vario_bin<CK_METRIC_HAVERSINE, 1><<<g, b, 0, s>>>(a);
+            k_vario_bin<CK_METRIC_HAVERSINE, 1><<<g, b, 0, s>>>(ad);
         else
-            k_vario_bin<CK_METRIC_HAVERSINE, 0><<<g, b, 0, s>>>(a);
+            k_vario_bin<CK_METRIC_HAVERSINE, 0><<<g, b, 0, s>>>(ad);
     } else {
         if (covariogram)
-            k_vario_bin<CK_METRIC_EUCLID, 1><<<g, b, 0, s>>>(a);
+            k_vario_bin<CK_METRIC_EUCLID, 1><<<g, b, 0, s>>>(ad);
         else
-            k_vario_bin<CK_METRIC_EUCLID, 0><<<g, b, 0, s>>>(a);
+            k_vario_bin<CK_METRIC_EUCLID, 0><<<g, b, 0, s>>>(ad);
     }
     k_vario_final<<<dim3(1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, covariogram ? 1.0 : 0.5, sums, counts);
 }

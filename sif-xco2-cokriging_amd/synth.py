@@ -82,3 +82,28 @@ def unit_square_problem(n: int, grid_side: int = 100, seed: int = 20002, params=
     gx, gy = np.meshgrid(g, g, indexing="ij")
     return dict(coords=[c0, c1], values=[z0, z1], pcoords=np.column_stack([gx.ravel(), gy.ravel()]),
                 params=list(params), metric=1)
+
+
+def residual_tables(n_sif: int = 47562, n_xco2: int = 23080, seed: int = 20001, params=SET_A):
+    """BASELINE config 1's input shape: gridded-residual tables with the column schema of the reference's
+    l2_north_america CSVs (l2_north_america/empirical_semivariogram.ipynb cell 3: lon, lat, evi, sif, lon_std, lat_std,
+    evi_std, ols_mean, sif_residuals, sif_residuals_std) and their row counts (47 562 SIF cells, 23 080 XCO2 cells of the
+    0.05-degree lattice, create_residuals.ipynb:732,1758).  The real files are not in the reference's repository
+    (.MISSING_LARGE_BLOBS); values here are synthetic (random cosine waves, see cosine_field_pair).  Returns two pandas
+    DataFrames (SIF, XCO2); write them with DataFrame.to_csv to rehearse the CSV plumbing."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    pts = lattice_sites(rng, n_sif + n_xco2 // 2)
+    c_sif = pts[:n_sif]
+    c_x = np.vstack([pts[:n_xco2 - n_xco2 // 2], pts[n_sif:]])          # half of the XCO2 cells are SIF cells too
+    z_sif, z_x = cosine_field_pair(np.random.default_rng(seed + 10000), c_sif, c_x, scale=6.0, rho=params[10])
+
+    def table(c, resid, name, sd):
+        n = len(c)
+        ols = 0.4 + 0.05 * np.cos(np.radians(c[:, 0]) * 3.0)
+        cols = {"lon": c[:, 1], "lat": c[:, 0], "evi": 0.3 + 0.1 * rng.standard_normal(n), name: ols + sd * resid,
+                "lon_std": np.full(n, 0.0144), "lat_std": np.full(n, 0.0144), "evi_std": 0.02 * np.ones(n), "ols_mean": ols,
+                f"{name}_residuals": sd * resid, f"{name}_residuals_std": resid}
+        return pd.DataFrame(cols)
+
+    return table(c_sif, z_sif * params[0], "sif", 0.17), table(c_x, z_x * params[1], "xco2", 1.1)
