@@ -14,7 +14,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libcokrige_hip.so")
+# CK_BUILD_OUT: build an EXPERIMENTAL library next to the product one (own object directory), to be loaded with
+# CK_LIB_PATH=<that file> (native.py) -- the product library is never overwritten by an experiment
+OUT = os.environ.get("CK_BUILD_OUT") or os.path.join(HERE, "libcokrige_hip.so")
 SOURCES = ["ck_api.hip", "ck_cov.hip", "ck_la.hip", "ck_vario.hip", "ck_local.hip", "ck_model.cpp"]
 ARCH = "gfx950"
 
@@ -38,7 +40,7 @@ def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cokrige.h"))
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
     flags += os.environ.get("CK_EXTRA_HIPCC_FLAGS", "").split()   # kernel experiments (-D...); use with --force

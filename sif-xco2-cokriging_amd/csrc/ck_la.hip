@@ -430,7 +430,8 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     __syncthreads();
 
     // (Tried: the chunk's barrier in the middle of its MFMAs with a second fragment set, so that every
-    // LDS read is issued 16 MFMAs before its use -- correct, 3 % slower than this plain order.)
+    // LDS read is issued 16 MFMAs before its use -- correct, 3 % slower than this plain order; s_setprio 1 around
+    // the chunk's MFMAs -- 1 % slower.)
     const int nst = np * NST;
     int pnl = 0, kc = 0;             // panel and chunk-in-panel of the chunk being PREFETCHED
     for (int st = 0; st < nst; ++st) {
