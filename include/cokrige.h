@@ -243,7 +243,7 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * the tiled path of ck_predict_local (batched 64-column steps on the matrix cores) instead of one workgroup per
  * point (in LDS up to 64 sites, on a global slab above);
  * "local_group" (1..16, default 4) = 64-column blocks per trailing update of that path;
- * "site_order" (0/1, default 1; set before the first assemble): 1 lays the sites of each process -- and
+ * "site_order" (0/1, default 1; changing it after the first assemble lays the sites out again): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
  * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,
  * less divergence in the exact evaluator).  Predictions, LOOCV results and variograms come back in the
@@ -251,7 +251,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * the order: L itself (ck_debug_get_lower; ck_sample therefore insists on site_order = 0), and the
  * index of the failing leading minor of a Sigma that is not positive definite -- ck_factor repeats such
  * a factorisation in the caller's order to report numpy's index; ck_panel_* callers get the index in
- * factorisation order. */
+ * factorisation order and can do the same by setting site_order = 0 and sweeping again
+ * (distributed.DistributedJoint does). */
 int ck_set_option(ck_handle* h, const char* name, int64_t value);
 /* Plain C -= A B^T on device buffers through the MFMA kernel (tests / microbenchmarks).
  * A: M x K (lda), B: N x K (ldb), C: M x N (ldc), all row-major device doubles;

@@ -2207,8 +2207,13 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "site_order")) {   // 0: caller's order | 1: Hilbert order (see ck_handle::site_order)
-        if (h->layout_ready && (value != 0) != (h->site_order != 0))
-            return fail("site_order must be set before the data are laid out (first assemble / predict)");
+        if (h->layout_ready && (value != 0) != (h->site_order != 0)) {
+            // same sizes, other order: the sites are laid out again on the next assemble (what ck_factor does on its own
+            // to report a failing minor in the caller's numbering; the step-wise driver does it through this option)
+            h->layout_ready = false;
+            h->assembled = h->factored = false;
+            h->aux_state = 0;
+        }
         h->site_order = value != 0;
         return 0;
     }

@@ -93,6 +93,7 @@ class DistributedJoint:
         self.timings = {}
         self._marks = _Marks(device)
         self._steps = []
+        self._caller_order = False   # set once a not-positive-definite Sigma has been re-swept in the caller's order
 
     # -- setup ------------------------------------------------------------------------------------
     def shard(self, m_total: int):
@@ -277,6 +278,12 @@ class DistributedJoint:
             info = min(infos)
             info = 0 if info >= 2 ** 62 else info
         if info != 0:
+            # every rank sees the same info.  scipy names the failing minor in the CALLER's site order: sweep once more
+            # in that order (as ck_factor does for one process); the handle then stays in it
+            if not self._caller_order and hasattr(h, "set_option"):
+                self._caller_order = True
+                h.set_option("site_order", 0)
+                return self.predict(i, pcoords)
             from numpy.linalg import LinAlgError
             raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
         return pred, err

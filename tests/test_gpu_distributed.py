@@ -133,6 +133,27 @@ def test_world1_driver_with_arena_matches_direct():
     assert np.max(np.abs(p1 - g["pred_R_1"])) / np.max(np.abs(g["pred_R_1"])) < 1e-9
 
 
+def test_step_wise_driver_reports_the_failing_minor_in_the_callers_order():
+    """A Sigma that is not positive definite: the step-wise driver (the form every rank of a multi-GPU run executes)
+    raises scipy's message with the minor index in the CALLER's site order -- it sweeps a second time with
+    site_order = 0, as ck_factor does for one process -- not in the library's Hilbert order."""
+    import torch
+    from numpy.linalg import LinAlgError
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.distributed import DistributedJoint
+    g = load_golden("joint_not_pd")
+    pv = g["params"]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(0)
+    h.set_data(0, g["coords0"], np.zeros(len(g["coords0"])))
+    h.set_data(1, g["coords1"], np.zeros(len(g["coords1"])))
+    r = DistributedJoint(h, 0, 1, device=torch.device("cuda", 0)).prepare(5)
+    with pytest.raises(LinAlgError) as e:
+        r.predict(0, g["coords0"][:5])
+    assert str(e.value) == str(g["message"])
+
+
 def _worker_vario_local(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
