@@ -203,16 +203,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 // wave owns a 64 x 32 quarter-strip (8 accumulator tiles = 64 VGPRs).  "Row image" LDS layout: 128-byte rows,
 // 16-byte k-pair p of row r in slot p ^ ((r >> 1) & 7), filled through registers (coalesced 128-byte global
 // rows, A negated on its way in), read with ds_read_b128 that hit every bank once per hardware lane group.
-template <int DUMMY>
+// CLIP: a wave whose 64 x 32 block lies entirely outside [0, row_lim) x [0, col_lim), or (lower) entirely above the
+// diagonal, skips its C traffic and its MFMAs (it still stages its share of the operands): the ragged systems of the
+// local predictor have a diagonal tile in every tile row and an overhang of up to 64 rows / columns.
+template <bool CLIP>
 __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, const double* __restrict__ A, long lda,
                                             const double* __restrict__ B, long ldb, long r0, long c0, int K,
-                                            char* lds) {
+                                            char* lds, long row_lim = 0, long col_lim = 0, bool lower = false) {
     constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
     constexpr int STAGE = 256 * 128;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
     const int li = lane & 15, g = lane >> 4;
+    const long wr = r0 + wm * 64, wc = c0 + wn * 32;
+    const bool active = !CLIP || (wr < row_lim && wc < col_lim && !(lower && wc > wr + 63));
 
     const ck_gchar* Ab = as_global(reinterpret_cast<const char*>(A + r0 * lda));
     const ck_gchar* Bb = as_global(reinterpret_cast<const char*>(B + c0 * ldb));
@@ -239,14 +244,16 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
         rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * b_step + b_src0);
     }
     d4_t acc[4][2];
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
+            for (int r = 0; r < 4; ++r) {
+                const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
-        }
+                for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
+            }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         *reinterpret_cast<d2_t*>(lds + s_dst0 + u * 8192) = -ra[u];
@@ -269,7 +276,7 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
         }
         const char* sb = lds + cur * STAGE;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2 && active; ++kb) {
             d2_t af[4], bf[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
@@ -298,6 +305,7 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
     // and, at the 128-VGPR budget of four waves per SIMD, spills them (22 VGPRs of scratch before this).
     ck_gdouble* Ce = Cb;
     asm volatile("" : "+s"(Ce));
+    if (!active) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_nt_e(double* __restrict__ C, lo
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (lower && r0 + 127 + diag_off < c0) return;
     const long y = blockIdx.y;
-    gemm_tile_e<0>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
+    gemm_tile_e<false>(C + y * sC, ldc, A + y * sA, lda, B + y * sB, ldb, r0, c0, K, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1034,7 +1042,7 @@ __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restri
     const int tn = t - tm * (tm + 1) / 2;
     double* S = slab + q.off;
     const double* A = S + (long)o * q.ld + g0;
-    gemm_tile_e<0>(S + (long)o * q.ld + o, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, K, lds);
+    gemm_tile_e<true>(S + (long)o * q.ld + o, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, K, lds, q.kq - o, q.kq - o, true);
 }
 
 // block i of the group at g0 for the first n_active systems (those with kq > g0 + 64 i)

@@ -248,8 +248,13 @@ def test_site_order_invariance(native):
         if so == 1:
             with pytest.raises(RuntimeError, match="site_order"):
                 h.sample(np.zeros(1400))
-            with pytest.raises(RuntimeError, match="site_order"):
-                h.set_option("site_order", 0)
+            # switching the order after the layout lays the sites out again on the next assemble
+            h.set_option("site_order", 0)
+            h.assemble_joint()
+            assert h.factor() == 0
+            again = h.predict(0, pb["pcoords"])
+            assert rel(again[0], pr[0][0]) < 1e-9 and rel(again[1], pr[0][1]) < 1e-9
+            assert np.array_equal(h.debug_site_order(0, 700), np.arange(700))
         h.close()
     for i in (0, 1):
         for a, b in zip(out[0][0][i] + out[0][1][i], out[1][0][i] + out[1][1][i]):
