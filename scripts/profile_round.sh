@@ -1,0 +1,25 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, on the GPU box:  scripts/profile_round.sh <tag>
+#   1. bench.py: rocprofv3 --kernel-trace --stats, then three separate --pmc passes (SQ, FETCH_SIZE, WRITE_SIZE)
+#   2. variogram (1 M soundings): kernel stats + SQ counters of the pair kernels
+#   3. local predictor (400 km): kernel stats + SQ counters of its matrix-core kernels
+# Outputs under gpurun_out/prof_<tag>*/ ; copy the summaries into profiles/ (scripts/collect_profiles.py).
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+scripts/profile_bench.sh $TAG > gpurun_out/prof_${TAG}_bench.txt 2>&1
+echo "bench profile done"
+scripts/prof_variogram.sh $TAG > gpurun_out/prof_${TAG}_vario_stats.txt 2>&1
+scripts/pmc_kernel.sh ${TAG}_vario "k_vario" scripts/bench_variogram.py 1000000 > gpurun_out/prof_${TAG}_vario_pmc.txt 2>&1
+echo "variogram profile done"
+scripts/prof_local.sh $TAG 20000 400 400 > gpurun_out/prof_${TAG}_local_stats.txt 2>&1
+scripts/pmc_kernel.sh ${TAG}_local "k_lt_|k_local" scripts/bench_local.py 20000 400 400 > gpurun_out/prof_${TAG}_local_pmc.txt 2>&1
+echo "local profile done"
+python3 bench.py --steps 10 --warmup 3 > gpurun_out/prof_${TAG}_bench_line.json 2> gpurun_out/prof_${TAG}_bench_line.err
+python3 bench.py --config 1 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench_config1.json 2>/dev/null
+python3 bench.py --n-obs 50000 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench_n50k.json 2>/dev/null
+python3 scripts/bench_variogram.py 1000000 > gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
+python3 scripts/bench_variogram.py 1000000 cross cpu >> gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
+python3 scripts/bench_local.py 20000 50 100 200 400 600 > gpurun_out/prof_${TAG}_local.json 2>/dev/null
+python3 scripts/bench_loocv.py > gpurun_out/prof_${TAG}_loocv.json 2>/dev/null
+echo "bench lines done"
