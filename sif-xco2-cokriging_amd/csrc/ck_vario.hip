@@ -217,10 +217,8 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
             }
             touched = true;
             const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
-#pragma unroll 4
-            for (long k = 0; k < jlen; ++k) {
-                const long j = js + k;   // uniform: scalar loads
-                const double r = pair_q(ax, ay, az, ju0[j], ju1[j], ju2[j]);
+            auto one = [&](long j, double bx, double by, double bz) __attribute__((always_inline)) {
+                const double r = pair_q(ax, ay, az, bx, by, bz);
                 if (live && (!a.same || j > i) && r <= qcap) {
                     if (r > rmax) {
                         rmax = r;
@@ -233,7 +231,21 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
                         jmin = j;
                     }
                 }
+            };
+            long k = 0;
+            for (; k + 4 <= jlen; k += 4) {   // four "j" points per round: one s_load_dwordx8 per coordinate array
+                const long j = js + k;        // uniform: scalar loads
+                double bx[4], by[4], bz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bx[u] = ju0[j + u];
+                    by[u] = ju1[j + u];
+                    bz[u] = ju2[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one(j + u, bx[u], by[u], bz[u]);
             }
+            for (; k < jlen; ++k) one(js + k, ju0[js + k], ju1[js + k], ju2[js + k]);
         }
         if (touched) {   // publish this wave's extremes so far: hints for every wave's tests above
             double wmax = rmax, wmin = rmin;
@@ -242,8 +254,12 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
                 wmin = fmin(wmin, __shfl_xor(wmin, off));
             }
             if (lane == 0) {
-                if (wmax > 0.0) atomicMax(&best[0], (unsigned long long)__double_as_longlong(wmax));
-                if (wmin < 1e300) atomicMin(&best[1], (unsigned long long)__double_as_longlong(wmin));
+                // only when it improves the published value: 5 120 waves hammering two addresses with an atomic per
+                // tile serialise at the L2 (the pass took 85 ms for a quarter of the binning pass's pairs)
+                const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
+                const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
+                if (wmax > bmax) atomicMax(&best[0], (unsigned long long)__double_as_longlong(wmax));
+                if (wmin < bmin) atomicMin(&best[1], (unsigned long long)__double_as_longlong(wmin));
             }
         }
     }
@@ -321,16 +337,28 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_collect(const VarioExtArgs a, 
                 if (!((qhi >= qtop_lo && qlo <= qcap) || qlo <= qbot_hi)) continue;
             }
             const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
-#pragma unroll 4
-            for (long k = 0; k < jlen; ++k) {
-                const long j = js + k;
-                const double q = pair_q(ax, ay, az, ju0[j], ju1[j], ju2[j]);
+            auto one = [&](long j, double bx, double by, double bz) __attribute__((always_inline)) {
+                const double q = pair_q(ax, ay, az, bx, by, bz);
                 const bool hit = (q >= qtop_lo && q <= qcap) || (q > 0.0 && q <= qbot_hi);
                 if (live && (!a.same || j > i) && hit) {
                     const unsigned at = atomicAdd(count, 1u);
                     if (at < cap) list[at] = CkVarioPair{(int)i, (int)j, 0, 0};
                 }
+            };
+            long k = 0;
+            for (; k + 4 <= jlen; k += 4) {
+                const long j = js + k;
+                double bx[4], by[4], bz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bx[u] = ju0[j + u];
+                    by[u] = ju1[j + u];
+                    bz[u] = ju2[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one(j + u, bx[u], by[u], bz[u]);
             }
+            for (; k < jlen; ++k) one(js + k, ju0[js + k], ju1[js + k], ju2[js + k]);
         }
     }
 }
@@ -640,18 +668,25 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs* __rest
     }
 }
 
-__global__ void k_vario_final(const double* __restrict__ part_sum, const unsigned long long* __restrict__ part_cnt,
-                              int nparts, int nb, double scale, double* __restrict__ sums, long long* __restrict__ counts) {
-    const int b = threadIdx.x;
+__global__ __launch_bounds__(64) void k_vario_final(const double* __restrict__ part_sum, const unsigned long long* __restrict__ part_cnt,
+                                                     int nparts, int nb, double scale, double* __restrict__ sums,
+                                                     long long* __restrict__ counts) {
+    // one workgroup (= one wave) per bin; the partials of a bin are summed in a fixed order: lane l takes p = l, l + 64, ...
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b > VG_MAXBINS || (b >= nb && b != VG_MAXBINS)) return;
     double s = 0.0;
     unsigned long long c = 0;
-    for (int p = 0; p < nparts; ++p) {
+    for (int p = lane; p < nparts; p += 64) {
         if (b < VG_MAXBINS) s += part_sum[(long)p * VG_MAXBINS + b];
         c += part_cnt[(long)p * (VG_MAXBINS + 1) + b];
     }
-    if (b < VG_MAXBINS) sums[b] = s * scale;
-    counts[b] = (long long)c;   // counts[VG_MAXBINS]: pairs visited
+    s = wave_sum(s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) {
+        if (b < VG_MAXBINS) sums[b] = s * scale;
+        counts[b] = (long long)c;   // counts[VG_MAXBINS]: pairs visited
+    }
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------------
@@ -759,7 +794,7 @@ void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, c
         else
             k_vario_bin<CK_METRIC_EUCLID, 0><<<g, b, 0, s>>>(ad);
     }
-    k_vario_final<<<dim3(1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, covariogram ? 1.0 : 0.5, sums, counts);
+    k_vario_final<<<dim3(VG_MAXBINS + 1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, covariogram ? 1.0 : 0.5, sums, counts);
 }
 
 // Workgroups of the three pair passes.  Wave tiles are dealt out with a fixed stride (deterministic sums), so every
