@@ -22,14 +22,29 @@ for trial in range(ntrial):
             p = rng.random((n, 2))
         if rng.random() < 0.3:
             p[: n // 10] = p[n // 2: n // 2 + n // 10]   # duplicated sites
+        if lattice:   # snap to a lattice: many pairs at exactly the same distance, ties on max_dist / on the edges
+            p = np.round(p * 60) / 60
         if metric == 0:
-            p = np.column_stack([25 + 25 * p[:, 0], -120 + 50 * p[:, 1]])
+            if world:     # whole globe incl. poles and the date line
+                p = np.column_stack([-90 + 180 * p[:, 0], -180 + 360 * p[:, 1]])
+            else:
+                p = np.column_stack([25 + 25 * p[:, 0], -120 + 50 * p[:, 1]])
+        else:
+            p = p * scale
         return p
+    lattice = bool(rng.random() < 0.4)
+    world = bool(rng.random() < 0.2)
+    scale = float(rng.choice([1.0, 1e3, 1e-3]))
     ci, cj = pts(ni), pts(nj)
     vi, vj = rng.standard_normal(ni), rng.standard_normal(nj)
     same = bool(rng.random() < 0.5)
     cov = bool(rng.random() < 0.3)
-    md = float(rng.choice([200.0, 600.0, 1500.0, 6000.0])) if metric == 0 else float(rng.choice([0.04, 0.15, 0.5, 3.0]))
+    md = float(rng.choice([200.0, 600.0, 1500.0, 6000.0, 25000.0])) if metric == 0 else float(rng.choice([0.04, 0.15, 0.5, 3.0])) * scale
+    if lattice and rng.random() < 0.6:   # max_dist = a distance that occurs in the data (the reference's own value of it)
+        a, b = int(rng.integers(0, ni)), int(rng.integers(0, ni))
+        d = float(orc.distance_matrix(ci[a:a + 1], ci[b:b + 1], metric)[0, 0])
+        if d > 0:
+            md = d
     nb = int(rng.choice([5, 12, 30, 36]))
     h = native.Handle(0)
     h.set_option("site_order", int(rng.integers(0, 2)))
@@ -40,12 +55,14 @@ for trial in range(ntrial):
         print(f"trial {trial}: skipped ({e})")
         continue
     ref = orc.variogram(ci, vi, ci if same else cj, vi if same else vj, same, metric, md, nb, cov)
-    ok = np.array_equal(got[3], ref[3])
+    ok = np.array_equal(got[3], ref[3]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])   # counts, edges, centres: exact
     has = ref[3] > 0
     dev = float(np.max(np.abs(got[2][has] - ref[2][has]) / np.maximum(1e-3, np.abs(ref[2][has])))) if has.any() else 0.0
     dev = max(dev, float(np.max(np.abs(got[1] - ref[1]) / np.maximum(1e-12, np.abs(ref[1]).max()))))
     worst = max(worst, dev)
-    tag = f"trial {trial}: metric {metric} n=({ni},{nj}) same {same} cov {cov} md {md} nb {nb} pairs {int(ref[3].sum())} -> dev {dev:.2e}"
+    st = h.vario_stats()
+    tag = (f"trial {trial}: metric {metric} n=({ni},{nj}) same {same} cov {cov} lattice {lattice} world {world} scale {scale} md {md} nb {nb} "
+           f"pairs {int(ref[3].sum())} host-decided {st['extent_host_pairs']}+{st['bin_host_pairs']} -> dev {dev:.2e}")
     print(tag, flush=True)
     if not ok or not (dev < 1e-9):
         print("MISMATCH", tag, got[3], ref[3])

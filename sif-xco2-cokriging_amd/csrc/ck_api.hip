@@ -869,7 +869,7 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     const int nJ = (Jhi - J0) / h->world + 1;
     (void)P;   // the group kernel reads panel K through d_panelptr[K] (own storage or receive buffer)
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad);
+    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad, h->nend);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -910,7 +910,7 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     timed = timed && h->time_gemm == 1;   // 2: only the Sigma updates are timed (one event list per sweep)
     (void)P;
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, rows);
+    ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, rows, h->nend);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -1006,14 +1006,14 @@ static int factor_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad);
+                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad, h->nend);
                     gemm_timed_end(h);
                 }
                 panel_factor_on(h, K0 + g, h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad);
+                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad, h->nend);
                 gemm_timed_end(h);
             }
         }
@@ -1050,7 +1050,7 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1));
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend);
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
@@ -1058,7 +1058,7 @@ static int solve_sweep(ck_handle* h) {
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
                 ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc,
-                                    aux_rows(h, K0 + Gc - 1));
+                                    aux_rows(h, K0 + Gc - 1), h->nend);
                 gemm_timed_end(h);
             }
         }
@@ -1258,15 +1258,16 @@ struct SchurSwap {
     std::vector<double*> sig;
     double **d_sigptr, **d_panelptr;
     int nK, time_gemm, world, rank;
-    int64_t Npad;
+    int64_t Npad, nend;
     long long* d_info;
     bool lookahead, assembled;
-    explicit SchurSwap(ck_handle* hh, int nJ, int64_t Mp) : h(hh) {
+    explicit SchurSwap(ck_handle* hh, int nJ, int64_t Mp, int64_t m_valid) : h(hh) {
         sig = h->sig;
         d_sigptr = h->d_sigptr;
         d_panelptr = h->d_panelptr;
         nK = h->nK;
         Npad = h->Npad;
+        nend = h->nend;
         d_info = h->d_info;
         time_gemm = h->time_gemm;
         lookahead = h->lookahead;
@@ -1277,6 +1278,7 @@ struct SchurSwap {
         h->d_sigptr = h->d_panelptr = h->d_sch_ptr;
         h->nK = nJ;
         h->Npad = Mp;
+        h->nend = m_valid;
         h->d_info = h->d_sch_info;
         h->time_gemm = 0;
         h->lookahead = false;
@@ -1290,6 +1292,7 @@ struct SchurSwap {
         h->d_panelptr = d_panelptr;
         h->nK = nK;
         h->Npad = Npad;
+        h->nend = nend;
         h->d_info = d_info;
         h->time_gemm = time_gemm;
         h->lookahead = lookahead;
@@ -1378,7 +1381,7 @@ extern "C" int ck_verify_model(ck_handle* h, int64_t* info) {
     HIPCHK(hipMemsetAsync(h->d_sch_info, 0, sizeof(long long), h->stream));
     long long v = 0;
     {
-        SchurSwap swap(h, nJ, Mp);
+        SchurSwap swap(h, nJ, Mp, m);
         if (factor_sweep(h)) return -1;   // records ev1 at its end
         HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

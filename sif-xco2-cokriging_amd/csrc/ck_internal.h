@@ -80,9 +80,9 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad);
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int64_t mrows);
+                         int nJ, int64_t mrows, int64_t nvalid);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur
 // complement (ck_verify_model); aux: np block columns of mpad x CK_NB solved right-hand-side rows
 void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,

@@ -486,7 +486,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d(double* const* __restrict__ sigptr,
                                                          double* const* __restrict__ srcptr, int K0, int np, int J0,
-                                                         int Jstep, long Npad) {
+                                                         int Jstep, long Npad, long nvalid) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
@@ -497,6 +497,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (r0 + 127 < c0) return;
+    // tiles entirely inside the identity padding behind the last site (up to 511 rows / columns): a padded row of L is
+    // zero left of its diagonal, so their update is exactly zero
+    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) return;
     const CkSrcSyrk src{srcptr, K0, J, r0, c0};
     gemm_tile_d<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
 }
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(double* __restrict__ aux, long mpad,
                                                         double* const* __restrict__ sigptr, int K0, int np, int J0,
-                                                        long mrows) {
+                                                        long mrows, long nvalid) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y;
     const int tiles_n = CK_NB / 128;
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(
     const int t = xcd_remap(blockIdx.x, nblk);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    if ((long)J * CK_NB + c0 >= nvalid) return;   // columns of the identity padding: the rows of L there are zero
     const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
     gemm_tile_d<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
@@ -559,20 +563,20 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the
 // block-column-cyclic stride of a multi-process run
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad) {
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad);
+    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid);
 }
 
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
 // sweep knows that the others are still zero in these columns
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int64_t mrows) {
+                         int nJ, int64_t mrows, int64_t nvalid) {
     if (nJ <= 0 || np <= 0 || mrows <= 0) return;
     const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows);
+    k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows, nvalid);
 }
 
 // plain (optionally batched over blockIdx.y) form
