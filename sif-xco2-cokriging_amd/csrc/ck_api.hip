@@ -1853,42 +1853,8 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     double best_lo = INFINITY, best_hi = -1.0;
     // Round 0 normally settles both extremes.  Further rounds only when every pair within the band of the largest
     // q <= cap turns out to lie beyond max_dist: the cap then moves below them.
-    for (int round = 0; round < 64 && !have_hi; ++round) {
-        ck_launch_vario_extent(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
-                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jb256, vario_cmax(cap), h->vg_best);
-        HIPCHK(hipGetLastError());
-        std::vector<CkVarioExt> part(h->vg_bgrid);
-        HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_bgrid * sizeof(CkVarioExt), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        CkVarioExt best = part[0];
-        for (int g = 1; g < h->vg_bgrid; ++g) {
-            if (part[g].rmin < best.rmin) {
-                best.rmin = part[g].rmin;
-                best.imin = part[g].imin;
-            }
-            if (part[g].rmax > best.rmax) {
-                best.rmax = part[g].rmax;
-                best.imax = part[g].imax;
-            }
-        }
-        if (best.imax < 0) break;   // no pair with q <= cap at all
-        // every pair whose q is within the band of an extreme is a candidate; the reference's formula decides
-        const double qtop_lo = best.rmax - 2.0 * vario_band(metric, best.rmax);
-        const double qbot_hi = (!have_lo && best.imin >= 0) ? best.rmin + 2.0 * vario_band(metric, best.rmin) : -1.0;
-        std::vector<CkVarioPair> cand;
-        for (int pass = 0; pass < 3; ++pass) {
-            HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
-            ck_launch_vario_collect(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, qtop_lo, cap,
-                                    qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib64, h->vg_jb,
-                                    h->vg_jb256);
-            HIPCHK(hipGetLastError());
-            bool overflow = false;
-            if (vario_fetch_list(h, cand, &overflow)) return -1;
-            if (!overflow) break;
-            if (pass == 2) return fail("variogram: candidate list kept overflowing");
-        }
-        h->vg_stats[0] += (int64_t)cand.size();
-        if (round) h->vg_stats[3] += 1;
+    // best_lo / best_hi over the candidates of one list
+    auto decide = [&](const std::vector<CkVarioPair>& cand) {
         const int64_t nc = (int64_t)cand.size();
         double tlo[8], thi[8];
         for (int t = 0; t < 8; ++t) {
@@ -1913,6 +1879,61 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
         }
         have_hi = best_hi >= 0.0;
         have_lo = best_lo < INFINITY;
+    };
+    for (int round = 0; round < 64 && !have_hi; ++round) {
+        // The pass lists, on its way, every pair in a thin window under the cap: with dense data the largest retained q
+        // lies inside it, and the candidates for the largest distance are then complete without a second pass.
+        const double win = fmax(1e-9 * cap, 8.0 * vario_band(metric, cap));
+        const double qwin_lo = cap - win;
+        HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
+        ck_launch_vario_extent(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
+                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jb256, vario_cmax(cap), h->vg_best, qwin_lo,
+                               h->vg_list, h->vg_count, h->vg_list_cap);
+        HIPCHK(hipGetLastError());
+        std::vector<CkVarioExt> part(h->vg_bgrid);
+        HIPCHK(hipMemcpyAsync(part.data(), h->vg_part, h->vg_bgrid * sizeof(CkVarioExt), hipMemcpyDeviceToHost, h->stream));
+        std::vector<CkVarioPair> wcand;
+        bool woverflow = false;
+        if (vario_fetch_list(h, wcand, &woverflow)) return -1;   // synchronises the stream
+        CkVarioExt best = part[0];
+        for (int g = 1; g < h->vg_bgrid; ++g) {
+            if (part[g].rmin < best.rmin) {
+                best.rmin = part[g].rmin;
+                best.imin = part[g].imin;
+            }
+            if (part[g].rmax > best.rmax) {
+                best.rmax = part[g].rmax;
+                best.imax = part[g].imax;
+            }
+        }
+        if (best.imax < 0) break;   // no pair with q <= cap at all
+        // every pair whose q is within the band of an extreme is a candidate; the reference's formula decides
+        double qtop_lo = best.rmax - 2.0 * vario_band(metric, best.rmax);
+        const double qbot_hi = (!have_lo && best.imin >= 0) ? best.rmin + 2.0 * vario_band(metric, best.rmin) : -1.0;
+        bool top_done = false;
+        if (!woverflow && qtop_lo >= qwin_lo) {   // the window holds every top candidate
+            h->vg_stats[0] += (int64_t)wcand.size();
+            decide(wcand);
+            top_done = have_hi;   // else: all of them beyond max_dist -> the full candidate pass below, then a lower cap
+        }
+        if (!top_done || qbot_hi > 0.0) {
+            std::vector<CkVarioPair> cand;
+            const double top_from = top_done ? INFINITY : qtop_lo;   // top candidates already decided: the bottom ones only
+            for (int pass = 0; pass < 3; ++pass) {
+                HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
+                ck_launch_vario_collect(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, top_from, cap,
+                                        qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib64, h->vg_jb,
+                                        h->vg_jb256);
+                HIPCHK(hipGetLastError());
+                bool overflow = false;
+                if (vario_fetch_list(h, cand, &overflow)) return -1;
+                if (!overflow) break;
+                if (pass == 2) return fail("variogram: candidate list kept overflowing");
+            }
+            h->vg_stats[0] += (int64_t)cand.size();
+            decide(cand);
+        }
+        if (round) h->vg_stats[3] += 1;
         if (!have_hi) {
             if (!(qtop_lo > 0.0)) break;
             cap = nextafter(qtop_lo, 0.0);   // everything from qtop_lo up is beyond max_dist

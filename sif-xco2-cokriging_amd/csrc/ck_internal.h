@@ -127,7 +127,9 @@ int ck_vario_bin_grid(int64_t ni, int64_t nj);   // workgroups of the three pair
 // ib64 / jb1024 / jb256: bounding balls of the 64-point "i" blocks, 1024-point "j" chunks and 256-point sub-chunks
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                             int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
-                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best /* 2 words */);
+                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best /* 2 words */,
+                            double qwin_lo /* pairs with qwin_lo <= q <= qcap go to the list */, CkVarioPair* list, unsigned* count,
+                            unsigned cap);
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                              int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
                              unsigned cap, int rank, int world, const double* ib64, const double* jb1024,

@@ -166,8 +166,12 @@ struct VarioExtArgs {
     double qcap, cmax;
 };
 
+// Pairs with qwin_lo <= q <= qcap are appended to `list` on the way: with dense data the largest retained q lies within
+// that thin window under the cap, and the host then has every candidate for the largest distance without a second pass.
 __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, VarioPartialExt* __restrict__ part,
-                                                          unsigned long long* best) {
+                                                          unsigned long long* best, double qwin_lo,
+                                                          CkVarioPair* __restrict__ list, unsigned* __restrict__ count,
+                                                          unsigned cap) {
     // best[0]: bit pattern of the largest retained q any wave has seen so far, best[1]: of the smallest positive
     // one (non-negative doubles order like their bit patterns).  A (sub-)tile whose bounding balls say that all its
     // pairs lie strictly inside (qlo, qhi) with qhi < best[0] and qlo > best[1] cannot change either extreme and is
@@ -220,6 +224,10 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
             auto one = [&](long j, double bx, double by, double bz) __attribute__((always_inline)) {
                 const double r = pair_q(ax, ay, az, bx, by, bz);
                 if (live && (!a.same || j > i) && r <= qcap) {
+                    if (r >= qwin_lo) {
+                        const unsigned at = atomicAdd(count, 1u);
+                        if (at < cap) list[at] = CkVarioPair{(int)i, (int)j, 0, 0};
+                    }
                     if (r > rmax) {
                         rmax = r;
                         imax = i;
@@ -721,13 +729,15 @@ static VarioExtArgs vario_ext_args(int same, const double* iu, int64_t ni, const
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                             int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
-                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best) {
+                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best, double qwin_lo,
+                            CkVarioPair* list, unsigned* count, unsigned cap) {
     // best: two words of device memory, initialised here to "nothing seen yet" (largest retained q = 0.0, smallest
     // positive q = the largest finite double)
     static const unsigned long long init[2] = {0ULL, 0x7fefffffffffffffULL};
     (void)hipMemcpyAsync(best, init, sizeof(init), hipMemcpyHostToDevice, s);
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
-        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part, best);
+        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part, best, qwin_lo,
+        list, count, cap);
 }
 
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
