@@ -19,6 +19,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("CK_BUILD_OUT") or os.path.join(HERE, "libcokrige_hip.so")
 SOURCES = ["ck_api.hip", "ck_cov.hip", "ck_la.hip", "ck_vario.hip", "ck_local.hip", "ck_model.cpp"]
 ARCH = "gfx950"
+# ck_vario.hip: the SLP vectoriser packs the binning kernel's per-pair slot counters into 16-bit lanes (v_perm /
+# v_pk_add_u16) -- more instructions than the v_addc chain it replaces
+EXTRA_FLAGS = {"ck_vario.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -49,7 +52,7 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src + ".o")
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+            cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1770,7 +1770,8 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
     CHKH(h);
     if (n_i <= 0 || !coords_i || !resid_i) return fail("bad field i");
     if (!same && (n_j <= 0 || !coords_j || !resid_j)) return fail("bad field j");
-    if (n_i >= (1LL << 31) || n_j >= (1LL << 31)) return fail("at most 2^31 - 1 points per field");
+    // the binning kernel addresses the "j" arrays with 32-bit byte offsets (8 n_j < 2^32) and lists pairs as int indices
+    if (n_i >= (1LL << 28) || n_j >= (1LL << 28)) return fail("at most 2^28 - 1 points per field");
     vario_free(h);
     h->vg_same = same ? 1 : 0;
     h->vg_ni = n_i;

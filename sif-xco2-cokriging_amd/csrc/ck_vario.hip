@@ -2,7 +2,7 @@
 //
 // Replaces MultiField._variogram_cloud + get_variogram's pd.cut/groupby
 // (src/fields.py:192-232, 378-386) without the dense n_i x n_j distance and cloud matrices:
-// every pair is visited in registers and accumulated into per-lane REGISTER accumulators.
+// every pair is visited in registers and accumulated into a small per-lane table in LDS.
 //
 // Distance.  The reference decides everything on the rounded distance d: `distance <= max_dist`, then
 // pd.cut on the edges (src/fields.py:212-216).  The kernels work on a monotone function q of d that needs
@@ -27,11 +27,12 @@
 // that passes level E is not retained.  One WAVE owns a pair tile of 64 "i" points (one per lane, in
 // registers) x 1024 "j" points (the same for every lane: scalar loads); per 256-point sub-chunk the bounding
 // balls of the two point blocks say which levels every pair passes (nlow) and which none can reach (> nhigh),
-// so a pair is compared against nhigh - nlow thresholds only -- with the points in Hilbert order 1 to 3.  A lane
-// keeps one sum and one count per bin of the window in registers (slot k = bin nlow + k): nested compares on the
-// way up, one FMA and one integer add where the pair stops.  They are reduced over the wave and added to the wave's
-// histogram in LDS only when nlow changes.  No LDS traffic and no atomics in the pair loop (the first version
-// kept per-lane histograms in LDS -- 113 KB, one wave per SIMD, two LDS atomics per pair).
+// so a pair is compared against nhigh - nlow thresholds only -- with the points in Hilbert order mostly 3 or 4 at
+// 30 bins over 1500 km.  A lane keeps one sum and one count per bin of the window (slot k = bin nlow + k) in its own
+// column of the wave's table in LDS: per level one subtraction whose sign bit is shifted into a word, then two LDS
+// atomics without return at slot = popcount of that word (see vario_round).  The table is reduced over the wave and
+// added to the wave's histogram only when nlow changes.  (Round 1 kept per-lane histograms of ALL bins in LDS -- 113 KB,
+// one wave per SIMD; the window keeps the table at 6 slots, 6.7 KB per wave, five waves per SIMD.)
 // Sums are deterministic: fixed tile -> wave assignment, fixed reduction orders.
 #include "ck_internal.h"
 
@@ -44,7 +45,7 @@
 #define VG_JSUB 256      // sub-chunk: unit of the level-window decision of the binning pass
 #define VG_IW 64         // "i" points of a wave tile (binning pass)
 #define VG_MAXBINS CK_VG_MAXBINS
-#define VG_SLOTS 9       // slot 0: base level (passed by every pair of the sub-chunk); slots 1..8 compared
+#define VG_SLOTS 6       // slot 0: base level (passed by every pair of the sub-chunk); slots 1..5 compared
 
 struct VarioPartialExt {
     double rmin, rmax;
@@ -151,6 +152,10 @@ __device__ __forceinline__ void tile_q_range(P ib, long nI, long bi, P jb, long 
 // while the kernels run.
 typedef const double __attribute__((address_space(4))) * vg_cptr;
 __device__ __forceinline__ vg_cptr vg_const(const double* p) { return (vg_cptr)(uintptr_t)p; }
+// the double at byte offset `off` of a constant-address-space array (scalar load: base + 32-bit offset register)
+__device__ __forceinline__ double vg_at(vg_cptr p, unsigned off) {
+    return *(vg_cptr)((const char __attribute__((address_space(4)))*)p + off);
+}
 
 // ---- pass 1a: extreme pairs in q-space --------------------------------------------------------------
 // Largest q <= qcap and smallest positive q over this process's pair tiles (qcap already carries the upper
@@ -413,105 +418,8 @@ __device__ __forceinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c,
     return false;
 }
 
-// Levels e0 + K .. e0 + NW for one pair.  Slot k accumulates the pairs of bin e0 + k, i.e. those that pass level
-// e0 + k and not level e0 + k + 1: a lane only compares on its way up and accumulates once, where it stops (the
-// first version accumulated CUMULATIVE sums at every level passed and took differences afterwards -- one FMA and one
-// add more per level, and for smooth fields, whose near bins hold much smaller cloud values than the far ones, the
-// differences lost up to six digits).
-// slot K += the pair.  The empty asm with the slot number as an immediate keeps the nine update sites DISTINCT for the
-// optimiser: identical, it merges them into one block that indexes the accumulators with a run-time slot number,
-// and the accumulators then live in scratch memory (measured: 165 -> 399 ms).
-template <int K>
-__device__ __forceinline__ void vario_acc(double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], double m1, double m2) {
-    S[K] = fma(m1, m2, S[K]);
-    C[K] += 1u;
-    asm volatile("" : : "n"(K));   // last in its block: code is merged from the end of the blocks backwards
-}
-
-template <int METRIC, int K, int NW>
-__device__ __forceinline__ void vario_chain(vg_args_ptr a, const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
-                                            double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], double x, double m1, double m2,
-                                            int e0, const VarioPairCtx& c) {
-    if constexpr (K <= NW) {
-        if (x > A[K]) {
-            vario_chain<METRIC, K + 1, NW>(a, A, B, S, C, x, m1, m2, e0, c);
-        } else {
-            // inside the band of level e0 + K: decided exactly (a pair that is above it cannot reach the next level).
-            // Slot 0 of a follow-up window is the previous window's last level: haversine pairs were listed there.
-            bool up = false;
-            if (x > B[K]) up = (K == 0 && METRIC == CK_METRIC_HAVERSINE) ? false : vario_near<METRIC>(a, c, e0 + K);
-            if (up)
-                vario_acc<K>(S, C, m1, m2);
-            else if (K > 0)   // K == 0: the pair belongs to the window below
-                vario_acc<(K > 0 ? K - 1 : 0)>(S, C, m1, m2);
-        }
-    } else {
-        vario_acc<NW>(S, C, m1, m2);   // passed every level of the window
-    }
-}
-
-// BASE: level e0 is passed by every pair of the sub-chunk (no compare).
-// NW: number of compared slots (window width).  CHECK: per-pair validity (ragged last block, diagonal).
-template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
-__device__ __forceinline__ void vario_pair(vg_args_ptr a, const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
-                                           double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], int e0, int same, double ax,
-                                           double ay, double az, double rx, double ry, double av, long i, bool live, long j,
-                                           double bx, double by, double bz, double bv) {
-    double x;
-    if (METRIC == CK_METRIC_HAVERSINE) {
-        x = fma(az, bz, fma(ay, by, ax * bx));   // (ax, ay, az) = -u_i
-    } else {
-        const double dx = ax - bx, dy = ay - by;
-        x = dx * dx + dy * dy;
-    }
-    double m1, m2;
-    if (COV) {
-        m1 = av;   // fields.py:382-383
-        m2 = bv;
-    } else {
-        m1 = m2 = av - bv;   // fields.py:384-385; the factor 0.5 is applied to the bin sums
-    }
-    const VarioPairCtx c{rx, ry, bx, by, i, j};
-    if (!CHECK || (live && (!same || j > i))) vario_chain<METRIC, BASE ? 1 : 0, NW>(a, A, B, S, C, x, m1, m2, e0, c);
-}
-
-// one 256-point sub-chunk against the wave's 64 "i" points
-template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
-__device__ __forceinline__ void vario_subchunk(vg_args_ptr a, vg_cptr ju0, vg_cptr ju1, vg_cptr ju2, vg_cptr jv,
-                                               const double (&A)[VG_SLOTS], const double (&B)[VG_SLOTS],
-                                               double (&S)[VG_SLOTS], unsigned (&C)[VG_SLOTS], int e0, int same, double ax,
-                                               double ay, double az, double rx, double ry, double av, long i, bool live,
-                                               long js, long jlen) {
-    long k = 0;
-    // Four "j" points per round: their scalar loads merge (s_load_dwordx8 per array).  (Fetching the next round's points
-    // a round ahead -- scalar loads return out of order, so a wave can only wait for all of them -- was measured and
-    // dropped: 32 more live SGPRs doubled the SGPR spills, 163 -> 199 ms.)
-    for (; k + 4 <= jlen; k += 4) {
-        const long j = js + k;
-        double bx[4], by[4], bz[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bx[u] = ju0[j + u];
-            by[u] = ju1[j + u];
-            bz[u] = METRIC == CK_METRIC_HAVERSINE ? ju2[j + u] : 0.0;
-            bv[u] = jv[j + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            vario_pair<METRIC, COV, NW, BASE, CHECK>(a, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, live, j + u, bx[u],
-                                                     by[u], bz[u], bv[u]);
-    }
-    for (; k < jlen; ++k) {
-        const long j = js + k;
-        vario_pair<METRIC, COV, NW, BASE, CHECK>(a, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, live, j, ju0[j], ju1[j],
-                                                 METRIC == CK_METRIC_HAVERSINE ? ju2[j] : 0.0, jv[j]);
-    }
-}
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the slot arrays are only ever indexed with
-// compile-time constants, so that they are split into registers before any loop is unrolled (a `for` loop over
-// them, even under #pragma unroll, kept them in scratch memory: by the time the loop was unrolled the optimiser had
-// merged the slots' identical update code into one block with a run-time index)
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the per-level arrays (band centres, in scalar
+// registers) are only ever indexed with compile-time constants
 template <class F, int... Is>
 __device__ __forceinline__ void vg_static_for(F&& f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -536,11 +444,187 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {   // wave
                             __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
+// ---- one round of "j" points against the wave's 64 "i" points -----------------------------------------------------
+// Slot k of a window accumulates the pairs of bin e0 + k: those that pass level e0 + k and not level e0 + k + 1.  Every
+// lane owns one column of a small table in LDS -- VG_SLOTS sums and counts -- and a pair costs it, per compared level:
+//   t = M - x          (M: the centre of the level's rounding band; sign bit set <=> "passed")           v_add_f64
+//   acc = acc << 1 | sign(t)                                                                             v_alignbit_b32
+//   dm = min(dm, |t|)  on the upper words of two levels at a time                                        1/2 v_min3_f32
+// then slot = popcount(acc) and two LDS atomics without return (ds_add_f64, ds_add_u32) at slot * stride + lane.  No
+// compare instruction, no branch, no lane mask, no update that most lanes sit out.  A pair within the band of a level
+// is rare: one test of dm per round sends the wave to the exact path, where Euclidean pairs are decided as the reference
+// would, haversine pairs are "not above" and go on the list for the host, and a pair whose exact side differs from its
+// sign rule is moved from one slot to the other.
+// How the kernel got here (1 M soundings, 1500 km, 30 bins; vector / scalar / LDS / branch instructions per 64-pair
+// step from the SQ counters; 83 % of the pairs sit in windows of three or four compared levels):
+//   round 1: per-lane tables of all 36 bins in LDS, 27 KB per wave, one wave per SIMD                         428 ms
+//   a branch per level and pair on the way up, slot accumulators in registers        19 / 22 / 0.5 / 8.5     147 ms
+//   the same without branches (lane masks, every slot's update under its mask)       26 / 23 / 0.5 / 1       147 ms
+//       -- the two tie: the SIMDs issue about one instruction per 3 cycles whatever the mix, and 2 (NW + 1) masked
+//          updates per pair, each idle in most lanes, cost what the branches did
+//   per-lane slot tables in LDS, slot number from v_cmp + v_addc per level             25 / 3 / 2.4 / 1      102 ms
+//   sign bits instead of compares, band test on upper words (this form)                19 / 3 / 2.4 / 1       87 ms
+// and now 82 % of the cycles are vector-ALU cycles (4 per instruction).  (The version before all of them accumulated
+// CUMULATIVE sums per level and took differences, which lost up to six digits on smooth fields.)
+#define VG_PLANE (VG_SLOTS * 64)   // doubles between a lane's sum and the cell of its count of the same slot
+// slot += (p, n): the count is a 32-bit integer in an 8-byte cell VG_PLANE doubles behind the sum, so that one
+// address register serves both atomics.  Measured (1 M soundings, bin pass): counts kept as doubles 91 ms (the second
+// atomic as slow as the first: the kernel ran at the LDS unit's rate); 32-bit counts in a plane of their own, 4-byte
+// cells, one more address computation per pair 89 ms; this form 87 ms.
+__device__ __forceinline__ void vario_put(double* ls, unsigned slot, double p, unsigned n) {
+    __hip_atomic_fetch_add(ls + slot * 64u, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((unsigned*)(ls + slot * 64u + VG_PLANE), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// dm = min(dm, |a|, |b|) on the HIGH WORDS of doubles read as floats: the bit patterns of non-negative doubles are
+// ordered like the numbers, and so are their upper halves (up to ties in the lower half); patterns that are NaNs as
+// floats belong to doubles beyond 2^1017 and drop out of a minimum.  Written as asm for the |.| input modifiers
+// without the canonicalisation the compiler's own float minimum would add.
+__device__ __forceinline__ void vario_min3abs(unsigned& dm, unsigned a, unsigned b) {
+    asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(dm) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void vario_min2abs(unsigned& dm, unsigned a) {
+    asm("v_min_f32_e64 %0, %0, |%1|" : "+v"(dm) : "v"(a));
+}
+
+// BASE: level e0 is passed by every pair of the sub-chunk (no compare).
+// NW: number of compared slots (window width).  CHECK: per-pair validity (ragged last block, diagonal).
+// ls: the lane's column of the wave's table (slot stride 64 doubles; counts VG_PLANE doubles behind the sums).
+// hmax_hi: upper half of a bound on every level's band half-width, rounded up.
+template <int METRIC, int COV, int NW, bool BASE, bool CHECK, int U>
+__device__ __forceinline__ void vario_round(vg_args_ptr a, const double (&M)[VG_SLOTS], unsigned hmax_hi, double xa_lane,
+                                            double xb_lane, double* ls, int e0, int same, double ax, double ay, double az,
+                                            double rx, double ry, double av, long i, bool live, long j,
+                                            const double (&bx)[U], const double (&by)[U], const double (&bz)[U],
+                                            const double (&bv)[U]) {
+    constexpr int K0 = BASE ? 1 : 0;        // first compared level of the window
+    constexpr int NL = NW - K0 + 1;         // compared levels
+    double x[U], p[U];
+    unsigned pop[U];
+    bool ok[U];
+    unsigned prev = 0u;          // a level's word waiting for its partner in the three-way minimum
+    unsigned dm = 0x7f800000u;   // +inf
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (METRIC == CK_METRIC_HAVERSINE) {
+            x[u] = fma(az, bz[u], fma(ay, by[u], ax * bx[u]));   // (ax, ay, az) = -u_i
+        } else {
+            const double dx = ax - bx[u], dy = ay - by[u];
+            x[u] = dx * dx + dy * dy;
+        }
+        if (COV) {
+            p[u] = av * bv[u];   // fields.py:382-383
+        } else {
+            const double d = av - bv[u];   // fields.py:384-385; the factor 0.5 is applied to the bin sums
+            p[u] = d * d;
+        }
+        ok[u] = true;
+        if (CHECK) {
+            ok[u] = live & (!same | (j + u > i));
+            x[u] = ok[u] ? x[u] : -INFINITY;   // passes no level, sits in no band
+        }
+        // per level: t = M - x (sign bit set <=> the pair is above the centre of the level's band: "passed", for now),
+        // the sign bits shifted into a word, |t| into the running minimum
+        unsigned acc = 0u;
+        vg_for<VG_SLOTS>([&](auto kc) {
+            constexpr int kk = kc.value;
+            if (kk >= K0 && kk <= NW) {
+                const double t = M[kk] - x[u];
+                const unsigned h = (unsigned)__double2hiint(t);
+                acc = __builtin_amdgcn_alignbit(acc, h, 31);   // (acc << 1) | sign
+                if ((u * NL + (kk - K0)) & 1)
+                    vario_min3abs(dm, prev, h);
+                else if (u * NL + (kk - K0) == U * NL - 1)
+                    vario_min2abs(dm, h);
+                else
+                    prev = h;
+            }
+        });
+        pop[u] = __builtin_popcount(acc);   // levels passed; BASE: = slot, else slot + 1 (level e0 itself is compared:
+        if (!BASE) ok[u] = ok[u] & (pop[u] > 0u);   // a pair that fails it belongs to the window below)
+    }
+    double* const lb = BASE ? ls : ls - 64;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (BASE && !CHECK)
+            vario_put(lb, pop[u], p[u], 1u);
+        else if (ok[u])
+            vario_put(lb, pop[u], p[u], 1u);
+    }
+    if (NL > 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(dm <= hmax_hi) != 0ull, 0)) {
+        // some lane has a pair close to a level: rare.  Inside the band (B, A] the pair is decided exactly and, where
+        // that differs from the sign rule above, moved: "above" belongs in slot kk, "not above" in slot kk - 1 (in none
+        // for kk = 0: the window below has it).  Haversine pairs are "not above" here and go on the list for the host
+        // -- once: level e0 of a follow-up window was listed as the previous window's last level.
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const VarioPairCtx c{rx, ry, bx[u], by[u], i, j + u};
+            vg_for<VG_SLOTS>([&](auto kc) {
+                constexpr int kk = kc.value;
+                if (kk >= K0 && kk <= NW) {
+                    const double Ak = lane_value(xa_lane, e0 + kk - 1), Bk = lane_value(xb_lane, e0 + kk - 1);
+                    if ((x[u] > Bk) & !(x[u] > Ak)) {
+                        const bool was = x[u] > M[kk];
+                        bool up = false;
+                        if (METRIC == CK_METRIC_EUCLID || kk > 0) up = vario_near<METRIC>(a, c, e0 + kk);
+                        if (up != was) {
+                            const double sg = up ? 1.0 : -1.0;
+                            const unsigned one = up ? 1u : ~0u;
+                            vario_put(ls, (unsigned)kk, sg * p[u], one);
+                            if (kk > 0) vario_put(ls, (unsigned)(kk > 0 ? kk - 1 : 0), -sg * p[u], 0u - one);
+                        }
+                    }
+                }
+            });
+        }
+    }
+}
+
+// one 256-point sub-chunk against the wave's 64 "i" points
+template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
+__device__ __forceinline__ void vario_subchunk(vg_args_ptr a, vg_cptr ju0, vg_cptr ju1, vg_cptr ju2, vg_cptr jv,
+                                               const double (&M)[VG_SLOTS], unsigned hmax_hi, double xa_lane,
+                                               double xb_lane, double* ls, int e0, int same, double ax, double ay,
+                                               double az, double rx, double ry, double av, long i, bool live, long js,
+                                               long jlen) {
+    // Four "j" points per round: their scalar loads merge (s_load_dwordx8 per array).  One 32-bit byte offset serves
+    // the four arrays (scalar loads take base + offset register; ck_vario_begin rejects more than 2^28 points): four
+    // 64-bit pointer increments and a 64-bit loop compare -- on the vector unit, there is no scalar one -- per round
+    // were a quarter of the loop's scalar instructions.  (Fetching the next round's points a round ahead -- scalar
+    // loads return out of order, so a wave can only wait for all of them, and that wait also covers the LDS atomics
+    // issued in between -- was measured twice and dropped: 163 -> 199 ms on the first version of the kernel,
+    // 87 -> 144 ms on this one.)
+    constexpr int UU = 4;
+    const unsigned n = (unsigned)jlen;
+    unsigned ob = (unsigned)js * 8u;
+    unsigned k = 0;
+    for (; k + UU <= n; k += UU, ob += 8u * UU) {
+        double bx[UU], by[UU], bz[UU], bv[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            bx[u] = vg_at(ju0, ob + 8u * u);
+            by[u] = vg_at(ju1, ob + 8u * u);
+            bz[u] = METRIC == CK_METRIC_HAVERSINE ? vg_at(ju2, ob + 8u * u) : 0.0;
+            bv[u] = vg_at(jv, ob + 8u * u);
+        }
+        vario_round<METRIC, COV, NW, BASE, CHECK, UU>(a, M, hmax_hi, xa_lane, xb_lane, ls, e0, same, ax, ay, az, rx, ry, av, i,
+                                                      live, js + k, bx, by, bz, bv);
+    }
+    for (; k < n; ++k, ob += 8u) {
+        const double bx[1] = {vg_at(ju0, ob)}, by[1] = {vg_at(ju1, ob)},
+                     bz[1] = {METRIC == CK_METRIC_HAVERSINE ? vg_at(ju2, ob) : 0.0}, bv[1] = {vg_at(jv, ob)};
+        vario_round<METRIC, COV, NW, BASE, CHECK, 1>(a, M, hmax_hi, xa_lane, xb_lane, ls, e0, same, ax, ay, az, rx, ry, av, i,
+                                                     live, js + k, bx, by, bz, bv);
+    }
+}
+
 // The arguments live in device memory and are read through the constant address space where they are needed
 // (scalar loads): as by-value kernel arguments their thirty pointers and sizes stayed in SGPRs for the whole kernel
 // and pushed the hot loop's thresholds and "j" points out into VGPR lanes (209 spilled SGPRs, 98 VGPRs).
+// (five waves per SIMD asked for: left alone the register allocator takes 101 VGPRs, four waves, 100 ms instead of 87;
+// at six -- 80 VGPRs, a few spills -- nothing is gained, the vector ALU is the limit by then)
 template <int METRIC, int COV>
-__global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs* __restrict__ args) {
+__global__ __launch_bounds__(VG_TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_vario_bin(
+    const VarioBinArgs* __restrict__ args) {
     const vg_args_ptr a = (vg_args_ptr)(uintptr_t)args;
     __shared__ double hsum[VG_TPB / 64][VG_MAXBINS];
     __shared__ unsigned long long hcnt[VG_TPB / 64][VG_MAXBINS + 1];   // [VG_MAXBINS]: visited pairs
@@ -557,29 +641,37 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs* __rest
     const long nwaves = (long)gridDim.x * (VG_TPB / 64), wid = (long)blockIdx.x * (VG_TPB / 64) + wv;
     const int world = a->world, rank = a->rank;
     const double cmax = a->cmax;
-    double S[VG_SLOTS];
-    unsigned C[VG_SLOTS];
+    // the wave's table: per lane one column of VG_SLOTS sums and, VG_PLANE doubles behind them, the cells of as many
+    // counts (only its own lane ever touches a column, so the no-return atomics are plain read-modify-writes executed by
+    // the LDS unit, in the lane's program order)
+    __shared__ double ltab[VG_TPB / 64][2 * VG_PLANE];
+    double* const ls = &ltab[wv][lane];
     vg_for<VG_SLOTS>([&](auto k) {
-        S[k.value] = 0.0;
-        C[k.value] = 0u;
+        ls[k.value * 64] = 0.0;
+        ls[VG_PLANE + k.value * 64] = 0.0;   // (the count's cell: all 8 bytes zero)
     });
+    // the centre of every level's band (lane e - 1) and a bound on all their half-widths (its upper word, rounded up)
+    const double xm_lane = lane < E ? 0.5 * (xa_lane + xb_lane) : INFINITY;
+    double hmax = lane < E ? 2.0 * (xa_lane - xb_lane) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, off));
+    const unsigned hmax_hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(hmax)) + 1u;
     int e0cur = -1;
     unsigned long long visited = 0;
-    // bins e0cur .. e0cur + 7 <- the slot accumulators, summed over the wave
-    // (always_inline: called from two places, and left as a call it would force the accumulators into scratch memory)
+    // bins e0cur .. e0cur + VG_SLOTS - 2 <- the table, summed over the wave
     auto flush = [&]() __attribute__((always_inline)) {
         if (e0cur >= 0) {
-            vg_for<VG_SLOTS - 1>([&](auto k) {   // slot 8 belongs to the follow-up window
-                const double sk = wave_sum(S[k.value]);
-                const unsigned ck = wave_sum_u(C[k.value]);
+            vg_for<VG_SLOTS - 1>([&](auto k) {   // the last slot belongs to the follow-up window
+                const double sk = wave_sum(ls[k.value * 64]);
+                const unsigned ck = wave_sum_u(*(const unsigned*)(ls + VG_PLANE + k.value * 64));
                 if (lane == 0 && e0cur + k.value < E) {
                     hsum[wv][e0cur + k.value] += sk;
                     hcnt[wv][e0cur + k.value] += (unsigned long long)ck;
                 }
             });
             vg_for<VG_SLOTS>([&](auto k) {
-                S[k.value] = 0.0;
-                C[k.value] = 0u;
+                ls[k.value * 64] = 0.0;
+                ls[VG_PLANE + k.value * 64] = 0.0;
             });
         }
     };
@@ -623,27 +715,22 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_bin(const VarioBinArgs* __rest
                     e0cur = e0;
                 }
                 const int nw = (nhigh - e0 < VG_SLOTS - 1) ? (nhigh - e0) : (VG_SLOTS - 1);   // compared slots
-                double A[VG_SLOTS], B[VG_SLOTS];
+                double M[VG_SLOTS];   // per compared level: the centre of its band
                 vg_for<VG_SLOTS>([&](auto k) {
                     const int lev = e0 + k.value;   // its thresholds sit in lane lev - 1
-                    if (lev >= 1 && lev <= nhigh) {
-                        A[k.value] = lane_value(xa_lane, lev - 1);
-                        B[k.value] = lane_value(xb_lane, lev - 1);
-                    } else {
-                        A[k.value] = B[k.value] = k.value > 0 ? INFINITY : -INFINITY;
-                    }
+                    M[k.value] = (lev >= 1 && lev <= nhigh) ? lane_value(xm_lane, lev - 1) : INFINITY;
                 });
                 const bool base = e0 == nlow;   // slot 0 = a level every pair passes (or the virtual level 0)
-#define VG_RUN(NWV)                                                                                                        \
-    if (check)                                                                                                             \
-        vario_subchunk<METRIC, COV, NWV, true, true>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay, az, rx, ry, av, i, \
-                                                     live, js, jlen);                                                      \
-    else                                                                                                                   \
-        vario_subchunk<METRIC, COV, NWV, true, false>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay, az, rx, ry, av,   \
-                                                      i, live, js, jlen);
+#define VG_RUN(NWV)                                                                                                       \
+    if (check)                                                                                                            \
+        vario_subchunk<METRIC, COV, NWV, true, true>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane, ls, e0, same, ax, \
+                                                     ay, az, rx, ry, av, i, live, js, jlen);                              \
+    else                                                                                                                  \
+        vario_subchunk<METRIC, COV, NWV, true, false>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane, ls, e0, same, ax, \
+                                                      ay, az, rx, ry, av, i, live, js, jlen);
                 if (!base) {
-                    vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, A, B, S, C, e0, same, ax, ay,
-                                                                           az, rx, ry, av, i, live, js, jlen);
+                    vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane, ls,
+                                                                           e0, same, ax, ay, az, rx, ry, av, i, live, js, jlen);
                 } else {
                     switch (nw) {
                     case 0: VG_RUN(0) break;
@@ -807,10 +894,10 @@ void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, c
     k_vario_final<<<dim3(VG_MAXBINS + 1), dim3(64), 0, s>>>(part_sum, part_cnt, grid, nb, covariogram ? 1.0 : 0.5, sums, counts);
 }
 
-// Workgroups of the three pair passes.  Wave tiles are dealt out with a fixed stride (deterministic sums), so every
-// workgroup should be resident from the start: with more workgroups than fit, the late ones begin when the first
-// finish and the tail of the launch runs half empty.  The binning kernel holds 5 waves per SIMD (83 VGPRs), i.e.
-// 5 four-wave workgroups per CU.
+// Workgroups of the three pair passes.  Wave tiles are dealt out with a fixed stride (deterministic sums) and their
+// cost varies (culled or not, window widths), so a wave should own many of them and a launch many more workgroups than
+// are resident at once (5 four-wave workgroups per CU: 93 VGPRs, 27 KB of LDS): the hardware then hands the next
+// workgroup to whichever CU is done, which balances the launch without making the sums depend on the timing.
 int ck_vario_bin_grid(int64_t ni, int64_t nj) {
     const int64_t nIw = (ni + VG_IW - 1) / VG_IW, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK;
     int64_t wgs = (nIw * nJ + (VG_TPB / 64) - 1) / (VG_TPB / 64);
@@ -820,7 +907,7 @@ int ck_vario_bin_grid(int64_t ni, int64_t nj) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    int per_cu = 5;   // measured at 1 M soundings, bin pass: 4 -> 166 ms, 5 -> 148, 6 -> 186, 8 -> 163
+    int per_cu = 80;   // measured at 1 M soundings, bin pass: 5 -> 98 ms, 20 -> 92, 40 -> 89, 80 -> 87
     if (const char* e = getenv("CK_VG_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // for that measurement
     const int64_t cap = (int64_t)cus * per_cu;
     return (int)(wgs < cap ? wgs : cap);

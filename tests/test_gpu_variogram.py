@@ -225,3 +225,70 @@ def test_variogram_wide_windows_many_bins():
         ids = np.searchsorted(ref[1], d, side="left")
         ids[d == 0] = 1
         assert np.array_equal(counts2, np.bincount(ids - 1, minlength=36)[:36])
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("ni,nj,same", [(2, 2, True), (3, 1, False), (1, 70, False), (63, 65, False), (65, 65, True),
+                                        (257, 1023, False), (1025, 1025, True), (2049, 5, False)])
+def test_variogram_ragged_sizes(metric, ni, nj, same):
+    """sizes below a wave, around the 64-row / 256- and 1024-column tile edges, and very unequal cross pairs."""
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.variogram import variogram_arrays
+    from oracle import cokrige_oracle as orc
+    rng = np.random.default_rng(100 * ni + nj + metric)
+    def pts(n):
+        p = rng.random((n, 2))
+        return np.column_stack([25 + 25 * p[:, 0], -120 + 50 * p[:, 1]]) if metric == 0 else p
+    ci, cj = pts(ni), pts(nj)
+    vi, vj = rng.standard_normal(ni), rng.standard_normal(nj)
+    md = 1e9 if ni * nj < 50 else (1800.0 if metric == 0 else 0.5)
+    for nb in (1, 2, 7):
+        try:
+            ref, exc = orc.variogram(ci, vi, ci if same else cj, vi if same else vj, same, metric, md, nb, False), None
+        except (ValueError, IndexError) as e:      # n_bins = 1 (no second centre), a single distance (zero width): the
+            ref, exc = None, type(e)               # reference's linspace / arange lines fail, and so must the mirror
+        h = native.Handle(0)
+        h.set_metric(metric)
+        try:
+            if exc is not None:
+                with pytest.raises(exc):
+                    variogram_arrays(h, ci, vi, None if same else cj, None if same else vj, same, md, nb)
+                continue
+            with np.errstate(all="ignore"):
+                got = variogram_arrays(h, ci, vi, None if same else cj, None if same else vj, same, md, nb)
+        finally:
+            h.close()
+        assert np.array_equal(got[3], ref[3])
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
+        has = ref[3] > 0
+        np.testing.assert_allclose(got[2][has], ref[2][has], rtol=1e-10, atol=1e-13)
+
+
+def test_variogram_degenerate_inputs():
+    """one site, or all sites identical: no pair of distinct sites in the marginal variogram -- the same
+    ValueError family the reference's pd.cut / np.linspace path ends in; the cross form keeps its zero lags."""
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.variogram import variogram_arrays
+    from oracle import cokrige_oracle as orc
+    h = native.Handle(0)
+    h.set_metric(0)
+    c1 = np.array([[40.0, -100.0]])
+    with pytest.raises(ValueError):
+        variogram_arrays(h, c1, np.array([1.0]), None, None, True, 500.0, 5)
+    cs = np.repeat(c1, 40, axis=0)
+    vs = np.arange(40.0)
+    with pytest.raises(ValueError):
+        variogram_arrays(h, cs, vs, None, None, True, 500.0, 5)
+    try:
+        ref = orc.variogram(cs, vs, cs, vs[::-1].copy(), False, 0, 500.0, 5, False)
+    except ValueError:
+        ref = None
+    if ref is None:
+        with pytest.raises(ValueError):
+            variogram_arrays(h, cs, vs, cs, vs[::-1].copy(), False, 500.0, 5)
+    else:
+        got = variogram_arrays(h, cs, vs, cs, vs[::-1].copy(), False, 500.0, 5)
+        assert np.array_equal(got[3], ref[3])
+        has = ref[3] > 0
+        np.testing.assert_allclose(got[2][has], ref[2][has], rtol=1e-12)
+    h.close()
