@@ -173,17 +173,39 @@ struct VarioExtArgs {
 
 // Pairs with qwin_lo <= q <= qcap are appended to `list` on the way: with dense data the largest retained q lies within
 // that thin window under the cap, and the host then has every candidate for the largest distance without a second pass.
+//
+// What the host needs of the two extremes is a bound each -- a value not above the largest retained q, one not below
+// the smallest positive q -- tight enough that the band it derives from them (ck_api.hip: ck_vario_extent) holds few
+// pairs; every pair inside those bands is then decided with the reference's arithmetic.  So the lanes track UPPER WORDS
+// only, as unsigned integers (non-negative doubles order like their bit patterns):
+//   top:    t = qcap - q; the smallest upper word of t.  A pair beyond the cap has t < 0, i.e. an upper word >= 2^31, and
+//           drops out of the minimum by itself;
+//   bottom: the smallest upper word of q (a zero distance, upper word 0, is dealt with on the rare path below).
+// Per round of four "j" points: 6 operations per pair for q, 1 for t, two three-way minima and two plain ones for the
+// eight upper words, one fold per extreme and one test -- a pair in the window, a zero distance? -- whose rare path
+// lists the window's pairs and folds the bottom exactly.  No branch per pair, no index bookkeeping (the first form:
+// three compares, a branch and up to six register moves per pair; ck_vario_extent as a whole 24.8 -> 15.6 ms at 1 M
+// soundings).
+__device__ __forceinline__ double vario_upper(unsigned hi) {   // a double >= every non-negative double with this upper word
+    return hi >= 0x7fefffffu ? INFINITY : __hiloint2double((int)(hi + 1u), 0);
+}
+__device__ __forceinline__ unsigned wave_min_u(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, VarioPartialExt* __restrict__ part,
-                                                          unsigned long long* best, double qwin_lo,
-                                                          CkVarioPair* __restrict__ list, unsigned* __restrict__ count,
-                                                          unsigned cap) {
-    // best[0]: bit pattern of the largest retained q any wave has seen so far, best[1]: of the smallest positive
-    // one (non-negative doubles order like their bit patterns).  A (sub-)tile whose bounding balls say that all its
-    // pairs lie strictly inside (qlo, qhi) with qhi < best[0] and qlo > best[1] cannot change either extreme and is
-    // skipped; a stale hint only makes the test more conservative.  Once the first waves have reported, what is left
-    // are the sub-tiles that straddle max_dist (largest retained lag) and those whose balls touch (smallest).
-    __shared__ double red_r[VG_TPB];
-    __shared__ long long red_i[VG_TPB], red_j[VG_TPB];
+                                                          unsigned* best, double qwin_lo, CkVarioPair* __restrict__ list,
+                                                          unsigned* __restrict__ count, unsigned cap) {
+    // best[0] / best[1]: the smallest upper word of t / of a positive q any wave has published so far.  A (sub-)tile whose
+    // bounding balls say that none of its pairs can have a smaller t or a smaller q is skipped; a stale hint only makes
+    // the test more conservative.  Once the first waves have reported, what is left are the sub-tiles that straddle
+    // max_dist (largest retained lag) and those whose balls touch (smallest).
+    __shared__ unsigned red[2][VG_TPB / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const vg_cptr ju0 = vg_const(a.ju0), ju1 = vg_const(a.ju1), ju2 = vg_const(a.ju2);
@@ -191,8 +213,13 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
     const long nIw = (ni + VG_IW - 1) / VG_IW, nJ = (nj + VG_JCHUNK - 1) / VG_JCHUNK, nJs = (nj + VG_JSUB - 1) / VG_JSUB;
     const long nwaves = (long)gridDim.x * (VG_TPB / 64), wid = (long)blockIdx.x * (VG_TPB / 64) + wv;
     const double qcap = a.qcap;
-    double rmin = 1e300, rmax = -1.0;
-    long long imin = -1, jmin = -1, imax = -1, jmax = -1;
+    const unsigned win_hi = (unsigned)__double2hiint(qcap - qwin_lo) + 1u;   // upper words of the t inside the window
+    unsigned utop = 0x7fffffffu, ubot = 0xffffffffu;                        // "none yet"
+    auto cannot_improve = [&](double qlo, double qhi) {
+        const double ttop = vario_upper(__atomic_load_n(&best[0], __ATOMIC_RELAXED));
+        const double rbot = vario_upper(__atomic_load_n(&best[1], __ATOMIC_RELAXED));
+        return (qcap - fmin(qhi, qcap) > ttop) && (qlo > rbot);
+    };
     for (long t = wid * a.world + a.rank; t < nIw * nJ; t += nwaves * a.world) {
         const long bi = t / nJ, bj = t - bi * nJ;
         const long i0 = bi * VG_IW, j0 = bj * VG_JCHUNK;
@@ -201,10 +228,7 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
             double dlo, qlo, qhi;
             tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jb), nJ, bj, &dlo, &qlo, &qhi);
             if (dlo > a.cmax) continue;   // no pair of this tile within max_dist
-            qhi = fmin(qhi, qcap);
-            const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
-            const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
-            if (qhi < bmax && qlo > bmin) continue;
+            if (cannot_improve(qlo, qhi)) continue;
         }
         const long i = i0 + lane;
         const bool live = i < ni;
@@ -219,99 +243,91 @@ __global__ __launch_bounds__(VG_TPB) void k_vario_extent(const VarioExtArgs a, V
                 double dlo, qlo, qhi;
                 tile_q_range(vg_const(a.ib), nIw, bi, vg_const(a.jsb), nJs, js / VG_JSUB, &dlo, &qlo, &qhi);
                 if (dlo > a.cmax) continue;
-                qhi = fmin(qhi, qcap);
-                const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
-                const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
-                if (qhi < bmax && qlo > bmin) continue;
+                if (cannot_improve(qlo, qhi)) continue;
             }
             touched = true;
-            const long jlen = (nj - js < VG_JSUB) ? (nj - js) : VG_JSUB;
-            auto one = [&](long j, double bx, double by, double bz) __attribute__((always_inline)) {
-                const double r = pair_q(ax, ay, az, bx, by, bz);
-                if (live && (!a.same || j > i) && r <= qcap) {
-                    if (r >= qwin_lo) {
-                        const unsigned at = atomicAdd(count, 1u);
-                        if (at < cap) list[at] = CkVarioPair{(int)i, (int)j, 0, 0};
+            const bool check = (i0 + VG_IW > ni) || (a.same && js < i0 + VG_IW);   // ragged last block, diagonal
+            const unsigned n = (unsigned)((nj - js < VG_JSUB) ? (nj - js) : VG_JSUB);
+            // one round of U "j" points
+            auto round = [&](auto uc, auto cc, unsigned k) __attribute__((always_inline)) {
+                constexpr int U = decltype(uc)::value;
+                constexpr bool CHECK = decltype(cc)::value;
+                double r[U], tt[U], bx[U], by[U], bz[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bx[u] = ju0[js + k + u];
+                    by[u] = ju1[js + k + u];
+                    bz[u] = ju2[js + k + u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    r[u] = pair_q(ax, ay, az, bx[u], by[u], bz[u]);
+                    if (CHECK) r[u] = (live && (!a.same || js + k + u > i)) ? r[u] : NAN;   // upper word 0x7ff8....: in no minimum
+                    tt[u] = qcap - r[u];
+                }
+                unsigned ut = (unsigned)__double2hiint(tt[0]), ub = (unsigned)__double2hiint(r[0]);
+#pragma unroll
+                for (int u = 1; u < U; ++u) {
+                    const unsigned ht = (unsigned)__double2hiint(tt[u]), hr = (unsigned)__double2hiint(r[u]);
+                    ut = ht < ut ? ht : ut;
+                    ub = hr < ub ? hr : ub;
+                }
+                utop = ut < utop ? ut : utop;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((ut <= win_hi) | (ub == 0u)) != 0ull, 0)) {
+                    // rare: a pair inside the window under the cap (listed for the host), or a zero distance (which
+                    // must not enter the bottom minimum)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (r[u] <= qcap && r[u] >= qwin_lo) {
+                            const unsigned at = atomicAdd(count, 1u);
+                            if (at < cap) list[at] = CkVarioPair{(int)i, (int)(js + k + u), 0, 0};
+                        }
+                        const unsigned hr = (unsigned)__double2hiint(r[u]);
+                        if (r[u] > 0.0 && hr < ubot) ubot = hr;
                     }
-                    if (r > rmax) {
-                        rmax = r;
-                        imax = i;
-                        jmax = j;
-                    }
-                    if (r > 0.0 && r < rmin) {
-                        rmin = r;
-                        imin = i;
-                        jmin = j;
-                    }
+                } else {
+                    ubot = ub < ubot ? ub : ubot;
                 }
             };
-            long k = 0;
-            for (; k + 4 <= jlen; k += 4) {   // four "j" points per round: one s_load_dwordx8 per coordinate array
-                const long j = js + k;        // uniform: scalar loads
-                double bx[4], by[4], bz[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    bx[u] = ju0[j + u];
-                    by[u] = ju1[j + u];
-                    bz[u] = ju2[j + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) one(j + u, bx[u], by[u], bz[u]);
+            unsigned k = 0;
+            if (check) {
+                for (; k + 4 <= n; k += 4) round(std::integral_constant<int, 4>{}, std::true_type{}, k);
+                for (; k < n; ++k) round(std::integral_constant<int, 1>{}, std::true_type{}, k);
+            } else {
+                for (; k + 4 <= n; k += 4) round(std::integral_constant<int, 4>{}, std::false_type{}, k);
+                for (; k < n; ++k) round(std::integral_constant<int, 1>{}, std::false_type{}, k);
             }
-            for (; k < jlen; ++k) one(js + k, ju0[js + k], ju1[js + k], ju2[js + k]);
         }
         if (touched) {   // publish this wave's extremes so far: hints for every wave's tests above
-            double wmax = rmax, wmin = rmin;
-            for (int off = 32; off > 0; off >>= 1) {
-                wmax = fmax(wmax, __shfl_xor(wmax, off));
-                wmin = fmin(wmin, __shfl_xor(wmin, off));
-            }
+            const unsigned wtop = wave_min_u(utop), wbot = wave_min_u(ubot);
             if (lane == 0) {
-                // only when it improves the published value: 5 120 waves hammering two addresses with an atomic per
-                // tile serialise at the L2 (the pass took 85 ms for a quarter of the binning pass's pairs)
-                const double bmax = __longlong_as_double((long long)__atomic_load_n(&best[0], __ATOMIC_RELAXED));
-                const double bmin = __longlong_as_double((long long)__atomic_load_n(&best[1], __ATOMIC_RELAXED));
-                if (wmax > bmax) atomicMax(&best[0], (unsigned long long)__double_as_longlong(wmax));
-                if (wmin < bmin) atomicMin(&best[1], (unsigned long long)__double_as_longlong(wmin));
+                // only when it improves the published value: thousands of waves hammering two addresses with an atomic
+                // per tile serialise at the L2 (the pass took 85 ms for a quarter of the binning pass's pairs)
+                if (wtop < __atomic_load_n(&best[0], __ATOMIC_RELAXED)) atomicMin(&best[0], wtop);
+                if (wbot < __atomic_load_n(&best[1], __ATOMIC_RELAXED)) atomicMin(&best[1], wbot);
             }
         }
     }
-    // workgroup reduction (min)
-    __syncthreads();
-    red_r[tid] = rmin;
-    red_i[tid] = imin;
-    red_j[tid] = jmin;
-    __syncthreads();
-    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
-        if (tid < s && red_r[tid + s] < red_r[tid]) {
-            red_r[tid] = red_r[tid + s];
-            red_i[tid] = red_i[tid + s];
-            red_j[tid] = red_j[tid + s];
-        }
-        __syncthreads();
+    // workgroup reduction; the partial result carries the two bounds as doubles and "a pair exists" in the index fields
+    const unsigned wtop = wave_min_u(utop), wbot = wave_min_u(ubot);
+    if (lane == 0) {
+        red[0][wv] = wtop;
+        red[1][wv] = wbot;
     }
+    __syncthreads();
     if (tid == 0) {
-        part[blockIdx.x].rmin = red_r[0];
-        part[blockIdx.x].imin = red_i[0];
-        part[blockIdx.x].jmin = red_j[0];
-    }
-    __syncthreads();
-    red_r[tid] = rmax;
-    red_i[tid] = imax;
-    red_j[tid] = jmax;
-    __syncthreads();
-    for (int s = VG_TPB / 2; s > 0; s >>= 1) {
-        if (tid < s && red_r[tid + s] > red_r[tid]) {
-            red_r[tid] = red_r[tid + s];
-            red_i[tid] = red_i[tid + s];
-            red_j[tid] = red_j[tid + s];
+        unsigned gt = red[0][0], gb = red[1][0];
+        for (int w = 1; w < VG_TPB / 64; ++w) {
+            gt = red[0][w] < gt ? red[0][w] : gt;
+            gb = red[1][w] < gb ? red[1][w] : gb;
         }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        part[blockIdx.x].rmax = red_r[0];
-        part[blockIdx.x].imax = red_i[0];
-        part[blockIdx.x].jmax = red_j[0];
+        const bool has_top = gt < 0x7ff00000u, has_bot = gb < 0x7ff00000u;
+        VarioPartialExt o;
+        o.rmax = has_top ? qcap - vario_upper(gt) : -1.0;   // <= the largest retained q of this workgroup's pairs
+        o.rmin = has_bot ? vario_upper(gb) : 1e300;         // >= the smallest positive one
+        o.imax = o.jmax = has_top ? 0 : -1;
+        o.imin = o.jmin = has_bot ? 0 : -1;
+        part[blockIdx.x] = o;
     }
 }
 
@@ -818,13 +834,12 @@ void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu,
                             int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
                             const double* jb1024, const double* jb256, double cmax, unsigned long long* best, double qwin_lo,
                             CkVarioPair* list, unsigned* count, unsigned cap) {
-    // best: two words of device memory, initialised here to "nothing seen yet" (largest retained q = 0.0, smallest
-    // positive q = the largest finite double)
-    static const unsigned long long init[2] = {0ULL, 0x7fefffffffffffffULL};
+    // best: two 32-bit words of device memory (the first 8 of its 16 bytes), initialised here to "nothing seen yet"
+    static const unsigned init[2] = {0x7fffffffu, 0xffffffffu};
     (void)hipMemcpyAsync(best, init, sizeof(init), hipMemcpyHostToDevice, s);
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
-        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part, best, qwin_lo,
-        list, count, cap);
+        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part,
+        (unsigned*)best, qwin_lo, list, count, cap);
 }
 
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
