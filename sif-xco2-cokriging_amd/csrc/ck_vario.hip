@@ -525,7 +525,7 @@ __device__ __forceinline__ void vario_round(vg_args_ptr a, const double (&M)[VG_
             x[u] = fma(az, bz[u], fma(ay, by[u], ax * bx[u]));   // (ax, ay, az) = -u_i
         } else {
             const double dx = ax - bx[u], dy = ay - by[u];
-            x[u] = dx * dx + dy * dy;
+            x[u] = fma(dx, dx, dy * dy);
         }
         if (COV) {
             p[u] = av * bv[u];   // fields.py:382-383
@@ -744,9 +744,15 @@ __global__ __launch_bounds__(VG_TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     else                                                                                                                  \
         vario_subchunk<METRIC, COV, NWV, true, false>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane, ls, e0, same, ax, \
                                                       ay, az, rx, ry, av, i, live, js, jlen);
-                if (!base) {
-                    vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane, ls,
-                                                                           e0, same, ax, ay, az, rx, ry, av, i, live, js, jlen);
+                if (!base) {   // a follow-up window of a sub-chunk that spans more than VG_SLOTS - 1 levels
+                    if (check)
+                        vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, true>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane,
+                                                                               ls, e0, same, ax, ay, az, rx, ry, av, i, live, js,
+                                                                               jlen);
+                    else
+                        vario_subchunk<METRIC, COV, VG_SLOTS - 1, false, false>(a, ju0, ju1, ju2, jv, M, hmax_hi, xa_lane, xb_lane,
+                                                                                ls, e0, same, ax, ay, az, rx, ry, av, i, live, js,
+                                                                                jlen);
                 } else {
                     switch (nw) {
                     case 0: VG_RUN(0) break;
