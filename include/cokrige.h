@@ -167,7 +167,7 @@ int ck_predict_local(ck_handle* h, int i, const double* pcoords_host, int64_t m,
 /* ---- empirical (cross-)semivariogram / covariogram: src/fields.py:192-232, 378-403 ----- */
 /* Fields i and j: coords (n x 2), residuals = values minus their mean (src/fields.py:380).
  * same != 0: marginal variogram, strict upper triangle of the i-i pairs (:195-199; j args ignored);
- * else all n_i * n_j pairs (:200-203).  Uses the handle's metric. */
+ * else all n_i * n_j pairs (:200-203).  Uses the handle's metric.  At most 2^28 - 1 points per field. */
 int ck_vario_begin(ck_handle* h, const double* coords_i_host, const double* resid_i_host, int64_t n_i,
                    const double* coords_j_host, const double* resid_j_host, int64_t n_j, int same);
 /* Pass 1: lo = smallest positive and hi = largest pair distance among pairs with d <= max_dist
