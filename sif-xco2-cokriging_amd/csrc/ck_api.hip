@@ -2040,8 +2040,30 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
             xb[e] = qb;
         }
         if (!(xb[e] < xa[e])) return fail("variogram bin edge below the resolution of the distances");
-        if (e > 1 && !(xb[e] > xa[e - 1])) return fail("variogram bin edges closer than the rounding band of the distances");
         q_reach = qa;
+    }
+    // Levels whose bands overlap (bins narrower than the rounding of the distances: max_dist equal to the smallest lattice
+    // distance makes linspace(lo, hi) a few 1e-15 wide, and the reference then bins by the last bits of its distances)
+    // form ONE level for the device, with the union of their bands; every pair inside it goes to the host, which walks
+    // it up through the cluster's edges with the reference's distance.  Device bin k = passed k clusters = real bin
+    // clast[k].  A cluster of one level is the ordinary case.
+    int cfirst[CK_VG_MAXBINS + 2], clast[CK_VG_MAXBINS + 2];
+    double cxa[CK_VG_MAXBINS + 2], cxb[CK_VG_MAXBINS + 2], cthr[CK_VG_MAXBINS + 2];
+    int EC = 0;
+    cfirst[0] = clast[0] = 0;
+    cxa[0] = cxb[0] = cthr[0] = 0.0;
+    for (int e = 1; e <= E; ++e) {
+        if (EC >= 1 && !(xb[e] > cxa[EC])) {   // overlaps the cluster so far
+            clast[EC] = e;
+            cxa[EC] = xa[e];
+            cthr[EC] = -1.0;   // not a single threshold: the device lists the pair also for the Euclidean metric
+        } else {
+            ++EC;
+            cfirst[EC] = clast[EC] = e;
+            cxa[EC] = xa[e];
+            cxb[EC] = xb[e];
+            cthr[EC] = dthr[e];
+        }
     }
     double* d_xa = h->vg_out;
     double* d_xb = h->vg_out + (CK_VG_MAXBINS + 2);
@@ -2049,18 +2071,18 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     double* d_sums = h->vg_out + 3 * (CK_VG_MAXBINS + 2);
     long long* d_cnt = (long long*)(d_sums + CK_VG_MAXBINS);
     void* d_args = (void*)(d_cnt + CK_VG_MAXBINS + 1);
-    HIPCHK(hipMemcpyAsync(d_xa, xa, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_xb, xb, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d_dthr, dthr, (E + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // xa / xb / dthr are stack arrays
+    HIPCHK(hipMemcpyAsync(d_xa, cxa, (EC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_xb, cxb, (EC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_dthr, cthr, (EC + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // the arrays are on the stack
     std::vector<CkVarioPair> fix;
     for (int pass = 0; pass < 3; ++pass) {
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         ck_launch_vario_bin(h->stream, metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv, h->vg_ni, h->vg_ju,
-                            h->vg_jv, h->vg_nj, E, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jb256,
+                            h->vg_jv, h->vg_nj, EC, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jb256,
                             h->vg_bgrid, h->vg_psum, h->vg_pcnt, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world,
-                            nb, d_sums, d_cnt, d_args);
+                            EC, d_sums, d_cnt, d_args);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         bool overflow = false;
@@ -2068,16 +2090,17 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
         if (!overflow) break;
         if (pass == 2) return fail("variogram: edge-pair list kept overflowing");
     }
-    long long cnt[CK_VG_MAXBINS + 1];
-    std::vector<double> sm(CK_VG_MAXBINS, 0.0);
-    HIPCHK(hipMemcpyAsync(sm.data(), d_sums, nb * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(cnt, d_cnt, (CK_VG_MAXBINS + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    long long dcn[CK_VG_MAXBINS + 1], cnt[CK_VG_MAXBINS + 1];
+    std::vector<double> dsm(CK_VG_MAXBINS, 0.0), sm(CK_VG_MAXBINS + 1, 0.0);
+    HIPCHK(hipMemcpyAsync(dsm.data(), d_sums, EC * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(dcn, d_cnt, (CK_VG_MAXBINS + 1) * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int b = E; b < nb; ++b) {   // bins above the cap hold nothing
-        sm[(size_t)b] = 0.0;
-        cnt[b] = 0;
+    for (int b = 0; b <= CK_VG_MAXBINS; ++b) cnt[b] = 0;
+    for (int k = 0; k < EC; ++k) {   // device bin k -> real bin clast[k] (< E: bins from the cap up hold nothing)
+        sm[(size_t)clast[k]] = dsm[(size_t)k];
+        cnt[clast[k]] = dcn[k];
     }
-    // Haversine: the pairs inside the band of a level were binned below it; the reference's formula on libm decides.
+    // The pairs inside the band of a level (cluster) were binned below it; the reference's formula on libm decides.
     if (!fix.empty()) {
         const int64_t nf = (int64_t)fix.size();
         std::vector<double> dsum((size_t)8 * (CK_VG_MAXBINS + 1), 0.0);
@@ -2087,16 +2110,19 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
             long long* dc = &dcnt[(size_t)t * (CK_VG_MAXBINS + 1)];
             for (int64_t k = a; k < b; ++k) {
                 const CkVarioPair& p = fix[(size_t)k];
-                if (p.lev < 1 || p.lev > E) continue;
+                if (p.lev < 1 || p.lev > EC) continue;
                 const double d = ref_distance(metric, &h->vg_ci[2 * (size_t)p.i], &h->vg_cj[2 * (size_t)p.j]);
-                if (!(d > dthr[p.lev])) continue;   // stays in the bin below the level
+                const int from = clast[p.lev - 1];   // where the device put it: below the cluster
+                int to = from;
+                for (int e = cfirst[p.lev]; e <= clast[p.lev] && d > dthr[e]; ++e) to = e;
+                if (to == from) continue;
                 const double va = h->vg_vi[(size_t)p.i], vb = h->vg_vj[(size_t)p.j];
                 const double cl = covariogram ? va * vb : 0.5 * ((va - vb) * (va - vb));   // src/fields.py:382-385
-                ds[p.lev - 1] -= cl;
-                dc[p.lev - 1] -= 1;
-                if (p.lev < E) {   // above the cap: not retained
-                    ds[p.lev] += cl;
-                    dc[p.lev] += 1;
+                ds[from] -= cl;
+                dc[from] -= 1;
+                if (to < E) {   // above the cap: not retained
+                    ds[to] += cl;
+                    dc[to] += 1;
                 }
             }
         });
@@ -2106,12 +2132,16 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
                 cnt[b] += dcnt[(size_t)t * (CK_VG_MAXBINS + 1) + b];
             }
     }
+    for (int b = E; b < nb; ++b) {   // bins above the cap hold nothing
+        sm[(size_t)b] = 0.0;
+        cnt[b] = 0;
+    }
     for (int b = 0; b < nb; ++b) {
         sums[b] = sm[(size_t)b];
         counts[b] = cnt[b];
     }
     h->vg_stats[1] = (int64_t)fix.size();
-    h->vg_stats[2] = cnt[CK_VG_MAXBINS];
+    h->vg_stats[2] = dcn[CK_VG_MAXBINS];
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[9] = ms;

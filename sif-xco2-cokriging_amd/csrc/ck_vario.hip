@@ -425,12 +425,19 @@ struct VarioPairCtx {
 };
 
 // Is the pair (within the band of level `lev`) above the threshold?  Euclidean: decided here, exactly as the
-// reference would; haversine: deferred to the host, here "not above".
+// reference would; haversine, and levels that stand for several edges closer together than the rounding of the
+// distances (dthr < 0, ck_api.hip: ck_vario_bin): deferred to the host -- listed, if `list_it` (level e0 of a
+// follow-up window was listed as the previous window's last level) -- and here "not above".
 template <int METRIC>
-__device__ __forceinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c, int lev) {
-    if (METRIC == CK_METRIC_EUCLID) return euclid_exact(c.ax, c.ay, c.bx, c.by) > vg_const(a->dthr)[lev];
-    const unsigned at = atomicAdd(a->count, 1u);
-    if (at < a->cap) a->list[at] = CkVarioPair{(int)c.i, (int)c.j, lev, 0};
+__device__ __forceinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c, int lev, bool list_it) {
+    if (METRIC == CK_METRIC_EUCLID) {
+        const double thr = vg_const(a->dthr)[lev];
+        if (thr >= 0.0) return euclid_exact(c.ax, c.ay, c.bx, c.by) > thr;
+    }
+    if (list_it) {
+        const unsigned at = atomicAdd(a->count, 1u);
+        if (at < a->cap) a->list[at] = CkVarioPair{(int)c.i, (int)c.j, lev, 0};
+    }
     return false;
 }
 
@@ -580,8 +587,7 @@ __device__ __forceinline__ void vario_round(vg_args_ptr a, const double (&M)[VG_
                     const double Ak = lane_value(xa_lane, e0 + kk - 1), Bk = lane_value(xb_lane, e0 + kk - 1);
                     if ((x[u] > Bk) & !(x[u] > Ak)) {
                         const bool was = x[u] > M[kk];
-                        bool up = false;
-                        if (METRIC == CK_METRIC_EUCLID || kk > 0) up = vario_near<METRIC>(a, c, e0 + kk);
+                        const bool up = vario_near<METRIC>(a, c, e0 + kk, kk > 0);
                         if (up != was) {
                             const double sg = up ? 1.0 : -1.0;
                             const unsigned one = up ? 1u : ~0u;

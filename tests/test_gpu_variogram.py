@@ -292,3 +292,50 @@ def test_variogram_degenerate_inputs():
         has = ref[3] > 0
         np.testing.assert_allclose(got[2][has], ref[2][has], rtol=1e-12)
     h.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("same", [True, False])
+def test_variogram_bins_narrower_than_the_rounding_of_the_distances(metric, same):
+    """max_dist = the smallest lattice distance: every retained pair has nominally the same distance, linspace(lo, hi)
+    is a few 1e-15 wide and the reference bins by the last bits of its distances -- so must the library (the edges'
+    bands overlap: the device treats them as one level and the host walks every pair through them)."""
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.variogram import variogram_arrays
+    from oracle import cokrige_oracle as orc
+    rng = np.random.default_rng(77 + metric)
+    if metric == 0:
+        la, lo = np.meshgrid(30 + 0.05 * np.arange(48), -110 + 0.05 * np.arange(60), indexing="ij")
+    else:
+        la, lo = np.meshgrid(0.1 * np.arange(48), 0.1 * np.arange(60), indexing="ij")
+    c = np.column_stack([la.ravel(), lo.ravel()])
+    v = rng.standard_normal(len(c))
+    keep = rng.random(len(c)) < 0.8
+    ci, vi = c[keep], v[keep]
+    cj, vj = c[~keep | (rng.random(len(c)) < 0.3)], rng.standard_normal(int((~keep | (rng.random(len(c)) < 0.3)).sum()))
+    cj = cj[: len(vj)]
+    d = orc.distance_matrix(ci, ci if same else cj, metric)
+    dmin = float(d[d > 0].min())
+    md = float(d[(d > 0) & (d < dmin * (1 + 1e-12))].max())   # the largest of the last-bit variants of the smallest distance
+    assert md > dmin
+    tried = 0
+    for nb in (5, 12):
+        try:
+            ref = orc.variogram(ci, vi, ci if same else cj, vi if same else vj, same, metric, md, nb, False)
+        except (ValueError, IndexError):
+            continue   # lo == hi exactly: the reference's arange fails
+        tried += 1
+        h = native.Handle(0)
+        h.set_metric(metric)
+        try:
+            with np.errstate(all="ignore"):
+                got = variogram_arrays(h, ci, vi, None if same else cj, None if same else vj, same, md, nb)
+            st = h.vario_stats()
+        finally:
+            h.close()
+        assert np.array_equal(got[3], ref[3]), (got[3], ref[3])
+        assert np.array_equal(got[1], ref[1])
+        has = ref[3] > 0
+        np.testing.assert_allclose(got[2][has], ref[2][has], rtol=1e-9, atol=1e-12)
+        assert st["bin_host_pairs"] > 0   # the pairs were decided on the host
+    assert tried > 0
