@@ -177,7 +177,7 @@ int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double* hi, int64
  * tiles (tile t belongs to rank t mod world): the host combines the ranks' results -- MIN of lo / MAX of hi
  * over the ranks that found a pair, SUM of the per-bin sums and counts (distributed.DistributedVariogram). */
 /* Pass 2: per-bin sum of cloud values and pair count for bins (e_b, e_b+1], first bin [0, e_1]
- * (pd.cut(include_lowest=True), :214-222); edges[0] must be 0; at most 36 bins.
+ * (pd.cut(include_lowest=True), :214-222); edges[0] must be 0; at most 60 bins.
  * cloud = 0.5 (a - b)^2, or a * b when covariogram != 0 (:378-386). */
 int ck_vario_bin(ck_handle* h, double max_dist, const double* edges_host, int n_edges, int covariogram,
                  double* sums_host, int64_t* counts_host);

@@ -45,7 +45,7 @@ for trial in range(ntrial):
         d = float(orc.distance_matrix(ci[a:a + 1], ci[b:b + 1], metric)[0, 0])
         if d > 0:
             md = d
-    nb = int(rng.choice([5, 12, 30, 36]))
+    nb = int(rng.choice([5, 12, 30, 36, 60]))
     h = native.Handle(0)
     h.set_option("site_order", int(rng.integers(0, 2)))
     h.set_metric(metric)

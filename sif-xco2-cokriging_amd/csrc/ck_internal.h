@@ -110,7 +110,7 @@ void ck_launch_mfma_probe(hipStream_t s, int32_t* out);
 int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters, double* sink);
 
 // ---- empirical variogram (ck_vario.hip) ----------------------------------------------------
-#define CK_VG_MAXBINS 36
+#define CK_VG_MAXBINS 60   // levels sit one per lane of a wave (ck_vario.hip); a few lanes of slack for the windows
 struct CkVarioExt {
     double rmin, rmax;
     long long imin, jmin, imax, jmax;

@@ -198,9 +198,10 @@ def test_variogram_large_lattice_vs_oracle(metric):
         np.testing.assert_allclose(got[2][ok], ref[2][ok], rtol=1e-10, atol=1e-13)
 
 
-def test_variogram_wide_windows_many_bins():
-    """Few points and many bins: one sub-chunk spans more than eight levels, so the binning pass walks several
-    windows of eight bins (and a cap below some of the caller's edges empties the bins above it)."""
+@pytest.mark.parametrize("nbins", [36, 60])
+def test_variogram_wide_windows_many_bins(nbins):
+    """Few points and many bins: one sub-chunk spans more levels than a window holds, so the binning pass walks several
+    windows (and a cap below some of the caller's edges empties the bins above it).  60 bins is the library's limit."""
     from sif_xco2_cokriging_amd import native
     from oracle import cokrige_oracle as orc
     rng = np.random.default_rng(29)
@@ -210,7 +211,7 @@ def test_variogram_wide_windows_many_bins():
     for metric, cc, md in ((0, c, 3000.0), (1, rng.random((n, 2)), 0.9)):
         h = native.Handle(0)
         h.set_metric(metric)
-        ref = orc.variogram(cc, v, cc, v, True, metric, md, 36)
+        ref = orc.variogram(cc, v, cc, v, True, metric, md, nbins)
         h.vario_begin(cc, v - v.mean())
         lo, hi, npos = h.vario_extent(md)
         assert (lo, hi) == (ref[0][0], ref[0][-1])
@@ -224,7 +225,7 @@ def test_variogram_wide_windows_many_bins():
         d = d[d <= cap]
         ids = np.searchsorted(ref[1], d, side="left")
         ids[d == 0] = 1
-        assert np.array_equal(counts2, np.bincount(ids - 1, minlength=36)[:36])
+        assert np.array_equal(counts2, np.bincount(ids - 1, minlength=nbins)[:nbins])
 
 
 @pytest.mark.parametrize("metric", [0, 1])
