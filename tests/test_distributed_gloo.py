@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) runs of the multi-process joint predictor on the gloo backend (CPU):
+"""world_size-2 (3, 4 and 8) runs of the multi-process joint predictor on the gloo backend (CPU):
 covers panel ownership, the broadcast schedule, prediction-point sharding, the result gather
 and the not-positive-definite path of sif-xco2-cokriging_amd/distributed.py.  The panel
 arithmetic is the numpy stand-in of tests/fake_panel_handle.py (the HIP kernels need a GPU and
@@ -84,7 +84,8 @@ def _run(world, case):
 
 
 @pytest.mark.parametrize("world,case", [(2, "solve"), (3, "solve"), (2, "solve_sequential"), (3, "solve_p2p"),
-                                        (4, "solve_p2p"), (3, "solve_p2p_sequential")])
+                                        (4, "solve_p2p"), (3, "solve_p2p_sequential"),
+                                        (8, "solve"), (8, "solve_p2p")])   # the node's size: more ranks than panels, empty pieces
 def test_joint_predict_two_ranks(world, case):
     """look-ahead schedule (asynchronous broadcast of panel K + 1 under the update by panel K) and the
     plain factor -> broadcast -> apply sequence; the panel exchange as one broadcast or as scatter + point-to-point
