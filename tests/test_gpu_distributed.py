@@ -35,8 +35,46 @@ class _GlooViaHost:
         for o, c in zip(outs, cs):
             o.copy_(c)
 
+    # point-to-point exchange (exchange="p2p"): gloo sends and receives host tensors only
+    isend, irecv = "isend", "irecv"
 
-def _worker(rank, world, port, q, via_host, big=False):
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def get_backend(self, group=None):
+        return "gloo"
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        d = self.d
+        works = []
+        for o in ops:
+            if o.op == "isend":
+                torch.cuda.synchronize()
+                hostbuf = o.tensor.cpu().contiguous()
+                w = d.isend(hostbuf, o.peer)
+                works.append(_HostWork(w, None, hostbuf))
+            else:
+                hostbuf = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                w = d.irecv(hostbuf, o.peer)
+                works.append(_HostWork(w, o.tensor, hostbuf))
+        return works
+
+
+class _HostWork:
+    def __init__(self, w, dev_tensor, hostbuf):
+        self.w, self.dev, self.hostbuf = w, dev_tensor, hostbuf
+
+    def wait(self):
+        self.w.wait()
+        if self.dev is not None:
+            self.dev.copy_(self.hostbuf)
+            self.dev = None
+        return True
+
+
+def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -64,7 +102,7 @@ def _worker(rank, world, port, q, via_host, big=False):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
-        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev).prepare(len(g["pcoords_A"]))
+        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange).prepare(len(g["pcoords_A"]))
         pred, err = r.predict(0, g["pcoords_A"])
         assert r.timings["update_ms"] > 0 and r.timings["bcast_wait_ms"] >= 0
         q.put((rank, pred, err, coords, values))
@@ -72,8 +110,10 @@ def _worker(rank, world, port, q, via_host, big=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("via_host,big", [(True, False), (False, False), (False, True)])
-def test_two_ranks_one_gpu_matches_oracle(via_host, big):
+@pytest.mark.parametrize("via_host,big,world,exchange", [(True, False, 2, "broadcast"), (False, False, 2, "broadcast"),
+                                                         (False, True, 2, "broadcast"), (True, True, 3, "p2p")])
+def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange):
+    """(the last case: three ranks, every panel scattered by its owner and passed on point to point)"""
     import torch.multiprocessing as mp
     from oracle import cokrige_oracle as orc
     s = socket.socket()
@@ -82,13 +122,13 @@ def test_two_ranks_one_gpu_matches_oracle(via_host, big):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, via_host, big)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, via_host, big, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _queue
     import time
     out, t0 = [], time.time()
-    while len(out) < 2:
+    while len(out) < world:
         try:
             out.append(q.get(timeout=2))
         except _queue.Empty:
