@@ -194,6 +194,12 @@ int ck_vario_stats(ck_handle* h, int64_t* out4, int n);
  * (A, B: n x 2), no GPU needed: */
 int ck_ref_distance(int metric, const double* A_host, const double* B_host, int64_t n, double* out_host);
 
+/* The order in which the library lays n sites out on the device (option site_order = 1, the default, and always
+ * for the variogram's points): along a Hilbert curve of order 16 through the sites' bounding box, sites of one cell
+ * in the caller's order.  perm_host[k] = index of the site that comes k-th.  Host-only (no handle, no device): the
+ * results of every entry point come back in the caller's order, so this is for inspection and tests. */
+int ck_hilbert_order(const double* coords_host, int64_t n, int64_t* perm_host);
+
 /* ---- diagnostics ------------------------------------------------------------- */
 /* Copy the locally owned part of Sigma / L back as a dense (N x N) lower triangle
  * (upper triangle zero-filled); small N only (tests).  Rows / columns are in the handle's INTERNAL

@@ -1807,6 +1807,18 @@ static double ref_distance(int metric, const double* a, const double* b) {
     return d * CK_EARTH_RADIUS_KM;
 }
 
+extern "C" int ck_hilbert_order(const double* coords, int64_t n, int64_t* perm_out) {
+    if (n < 0 || (n > 0 && (!coords || !perm_out))) return fail("bad arguments");
+    if (n >= (1LL << 32)) return fail("at most 2^32 - 1 sites");
+    if (n == 0) return 0;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    bounding_box(coords, n, lo, hi);
+    std::vector<int64_t> perm;
+    hilbert_order(coords, n, lo, hi, perm);
+    memcpy(perm_out, perm.data(), (size_t)n * sizeof(int64_t));
+    return 0;
+}
+
 extern "C" int ck_ref_distance(int metric, const double* A, const double* B, int64_t n, double* out) {
     if (metric != CK_METRIC_HAVERSINE && metric != CK_METRIC_EUCLID) return fail("unknown metric");
     if (n > 0 && (!A || !B || !out)) return fail("null array");

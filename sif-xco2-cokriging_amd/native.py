@@ -64,6 +64,7 @@ _PROTOS = {
     "ck_vario_end": [c_void_p],
     "ck_vario_stats": [c_void_p, POINTER(c_int64), c_int],
     "ck_ref_distance": [c_int, _dp, _dp, c_int64, _dp],
+    "ck_hilbert_order": [_dp, c_int64, POINTER(c_int64)],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
     "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
@@ -153,6 +154,15 @@ def ref_distance(metric: int, A, B):
     out = np.empty(A.shape[0])
     _chk(lib().ck_ref_distance(int(metric), _p(A), _p(B), A.shape[0], _p(out)))
     return out
+
+
+def hilbert_order(coords):
+    """Indices of the sites in the order the library lays them out on the device (include/cokrige.h: ck_hilbert_order;
+    host only)."""
+    c = _f64(coords, 2)
+    perm = np.empty(c.shape[0], dtype=np.int64)
+    _chk(lib().ck_hilbert_order(_p(c), c.shape[0], perm.ctypes.data_as(POINTER(c_int64))))
+    return perm
 
 
 def device_count() -> int:
