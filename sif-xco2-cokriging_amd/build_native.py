@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cokrige.h"))
     objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"] + os.environ.get("CK_BUILD_DEFS", "").split()
     flags += os.environ.get("CK_EXTRA_HIPCC_FLAGS", "").split()   # kernel experiments (-D...); use with --force
 
     def compile_one(src):

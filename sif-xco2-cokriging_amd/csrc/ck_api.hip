@@ -144,8 +144,8 @@ struct ck_handle {
                                                       // (the pairs the kernels leave to the host are decided on these)
     double *vg_iu = nullptr, *vg_iv = nullptr, *vg_ju = nullptr, *vg_jv = nullptr;
     unsigned long long* vg_best = nullptr;       // extreme-pair hints of the extent pass (ck_vario.hip)
-    double *vg_jb = nullptr, *vg_ib64 = nullptr, *vg_jb256 = nullptr;   // bounding balls: 1024-point "j" chunks, 64-point
-                                                                        // "i" blocks (wave tiles), 256-point sub-chunks
+    double *vg_jb = nullptr, *vg_ib64 = nullptr, *vg_jbsub = nullptr;   // bounding balls: 1024-point "j" chunks, 64-point
+                                                                        // "i" blocks (wave tiles), 128-point sub-chunks
     int64_t vg_ni = 0, vg_nj = 0;
     int vg_same = 0, vg_bgrid = 0;
     void* vg_part = nullptr;
@@ -1736,12 +1736,12 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
 // ---------------------------------------------------------------------------------------
 static void vario_free(ck_handle* h) {
     void* ps[] = {h->vg_iu, h->vg_iv, h->vg_same ? nullptr : h->vg_ju, h->vg_same ? nullptr : h->vg_jv,
-                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_jb, h->vg_ib64, h->vg_jb256,
+                  h->vg_part, h->vg_psum, h->vg_pcnt, h->vg_out, h->vg_jb, h->vg_ib64, h->vg_jbsub,
                   h->vg_best, h->vg_list, h->vg_count};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     h->vg_iu = h->vg_iv = h->vg_ju = h->vg_jv = nullptr;
-    h->vg_jb = h->vg_ib64 = h->vg_jb256 = nullptr;
+    h->vg_jb = h->vg_ib64 = h->vg_jbsub = nullptr;
     h->vg_best = nullptr;
     h->vg_part = nullptr;
     h->vg_psum = nullptr;
@@ -1872,11 +1872,11 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
     }
     HIPCHK(hipMalloc((void**)&h->vg_ib64, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 64) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1024) * 8)));
-    HIPCHK(hipMalloc((void**)&h->vg_jb256, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 256) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_jbsub, (size_t)(4 * ck_vario_nblocks(h->vg_nj, CK_VG_JSUB) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_best, 16));
     ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 64, h->vg_ib64);
     ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1024, h->vg_jb);
-    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 256, h->vg_jb256);
+    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, CK_VG_JSUB, h->vg_jbsub);
     HIPCHK(hipGetLastError());
     h->vg_bgrid = ck_vario_bin_grid(h->vg_ni, h->vg_nj);
     HIPCHK(hipMalloc(&h->vg_part, h->vg_bgrid * sizeof(CkVarioExt)));
@@ -1958,7 +1958,7 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
         const double qwin_lo = cap - win;
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         ck_launch_vario_extent(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
-                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jb256, vario_cmax(cap), h->vg_best, qwin_lo,
+                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jbsub, vario_cmax(cap), h->vg_best, qwin_lo,
                                h->vg_list, h->vg_count, h->vg_list_cap);
         HIPCHK(hipGetLastError());
         std::vector<CkVarioExt> part(h->vg_bgrid);
@@ -1994,7 +1994,7 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
                 HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
                 ck_launch_vario_collect(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, top_from, cap,
                                         qbot_hi, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world, h->vg_ib64, h->vg_jb,
-                                        h->vg_jb256);
+                                        h->vg_jbsub);
                 HIPCHK(hipGetLastError());
                 bool overflow = false;
                 if (vario_fetch_list(h, cand, &overflow)) return -1;
@@ -2092,7 +2092,7 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         ck_launch_vario_bin(h->stream, metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv, h->vg_ni, h->vg_ju,
-                            h->vg_jv, h->vg_nj, EC, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jb256,
+                            h->vg_jv, h->vg_nj, EC, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jbsub,
                             h->vg_bgrid, h->vg_psum, h->vg_pcnt, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world,
                             EC, d_sums, d_cnt, d_args);
         HIPCHK(hipGetLastError());

@@ -110,6 +110,11 @@ void ck_launch_mfma_probe(hipStream_t s, int32_t* out);
 int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters, double* sink);
 
 // ---- empirical variogram (ck_vario.hip) ----------------------------------------------------
+#ifndef CK_VG_JSUB
+#define CK_VG_JSUB 128   // "j" points of a sub-chunk: the unit of the level-window decision (and of the third set of bounding
+                         // balls).  Bin pass at 1 M soundings: 64 -> 85.5 ms, 128 -> 80.9, 256 -> 87.1, 512 -> 122.5 (smaller blocks,
+                         // narrower windows, more set-up); at 4 M soundings 128 and 256 are within 2 %
+#endif
 #define CK_VG_MAXBINS 60   // levels sit one per lane of a wave (ck_vario.hip); a few lanes of slack for the windows
 struct CkVarioExt {
     double rmin, rmax;
@@ -124,16 +129,16 @@ void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int me
                           double* u2);
 int ck_vario_bin_grid(int64_t ni, int64_t nj);   // workgroups of the three pair passes (wave tiles of 64 x 1024 points)
 // iu / ju: 3 x n SoA (unit vectors | x, y, 0); part: CkVarioExt[grid]; q = squared chord | squared distance;
-// ib64 / jb1024 / jb256: bounding balls of the 64-point "i" blocks, 1024-point "j" chunks and 256-point sub-chunks
+// ib64 / jb1024 / jbsub: bounding balls of the 64-point "i" blocks, 1024-point "j" chunks and 128-point sub-chunks
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                             int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
-                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best /* 2 words */,
+                            const double* jb1024, const double* jbsub, double cmax, unsigned long long* best /* 2 words */,
                             double qwin_lo /* pairs with qwin_lo <= q <= qcap go to the list */, CkVarioPair* list, unsigned* count,
                             unsigned cap);
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                              int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
                              unsigned cap, int rank, int world, const double* ib64, const double* jb1024,
-                             const double* jb256);
+                             const double* jbsub);
 // tile culling (ck_vario.hip): bounding balls of blocks of `blk` consecutive points, 4 x nblk doubles
 int64_t ck_vario_nblocks(int64_t n, int blk);
 void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, double* out);
@@ -143,7 +148,7 @@ void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, 
 void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, const double* iu, const double* iv,
                          int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* xa,
                          const double* xb, const double* dthr, double cmax, const double* ib64, const double* jb1024,
-                         const double* jb256, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
+                         const double* jbsub, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
                          unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts,
                          void* args_dev);
 

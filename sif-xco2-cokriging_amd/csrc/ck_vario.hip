@@ -25,7 +25,7 @@
 // Pass 2.  "Levels" 1 .. E are the thresholds in ascending order: the inner edges below the cap, then the
 // cap min(max_dist, last edge); the bin of a pair is the number of levels it passes (d > threshold), a pair
 // that passes level E is not retained.  One WAVE owns a pair tile of 64 "i" points (one per lane, in
-// registers) x 1024 "j" points (the same for every lane: scalar loads); per 256-point sub-chunk the bounding
+// registers) x 1024 "j" points (the same for every lane: scalar loads); per 128-point sub-chunk the bounding
 // balls of the two point blocks say which levels every pair passes (nlow) and which none can reach (> nhigh),
 // so a pair is compared against nhigh - nlow thresholds only -- with the points in Hilbert order mostly 3 or 4 at
 // 30 bins over 1500 km.  A lane keeps one sum and one count per bin of the window (slot k = bin nlow + k) in its own
@@ -42,7 +42,7 @@
 
 #define VG_TPB 256
 #define VG_JCHUNK 1024   // "j" points of a pair tile
-#define VG_JSUB 256      // sub-chunk: unit of the level-window decision of the binning pass
+#define VG_JSUB CK_VG_JSUB   // sub-chunk: unit of the level-window decision of the binning pass
 #define VG_IW 64         // "i" points of a wave tile (binning pass)
 #define VG_MAXBINS CK_VG_MAXBINS
 #define VG_SLOTS 6       // slot 0: base level (passed by every pair of the sub-chunk); slots 1..5 compared
@@ -160,14 +160,14 @@ __device__ __forceinline__ double vg_at(vg_cptr p, unsigned off) {
 // ---- pass 1a: extreme pairs in q-space --------------------------------------------------------------
 // Largest q <= qcap and smallest positive q over this process's pair tiles (qcap already carries the upper
 // band of max_dist: the host decides the pairs near it).  Same tiling as the binning pass: a wave owns 64 "i"
-// points x 1024 "j" points and decides per 256-point sub-chunk whether it can hold a new extreme.
+// points x 1024 "j" points and decides per 128-point sub-chunk whether it can hold a new extreme.
 struct VarioExtArgs {
     int same, rank, world;
     const double *iu0, *iu1, *iu2;
     long ni;
     const double *ju0, *ju1, *ju2;
     long nj;
-    const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 256-point sub-chunks
+    const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 128-point sub-chunks
     double qcap, cmax;
 };
 
@@ -410,7 +410,7 @@ struct VarioBinArgs {
     const double* xb;     // [1 .. nlev]: x <= xb[e]: certainly not
     const double* dthr;   // [1 .. nlev]: the threshold as a distance (edge or cap), for the exact decision
     double cmax;          // largest chord that can reach the band of the cap
-    const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 256-point sub-chunks
+    const double *ib, *jb, *jsb;   // bounding balls: 64-point "i" blocks, 1024-point "j" chunks, 128-point sub-chunks
     double* part_sum;
     unsigned long long* part_cnt;   // per workgroup: VG_MAXBINS counts + [VG_MAXBINS] visited pairs
     CkVarioPair* list;
@@ -601,7 +601,7 @@ __device__ __forceinline__ void vario_round(vg_args_ptr a, const double (&M)[VG_
     }
 }
 
-// one 256-point sub-chunk against the wave's 64 "i" points
+// one 128-point sub-chunk against the wave's 64 "i" points
 template <int METRIC, int COV, int NW, bool BASE, bool CHECK>
 __device__ __forceinline__ void vario_subchunk(vg_args_ptr a, vg_cptr ju0, vg_cptr ju1, vg_cptr ju2, vg_cptr jv,
                                                const double (&M)[VG_SLOTS], unsigned hmax_hi, double xa_lane,
@@ -821,7 +821,7 @@ void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int me
 
 static VarioExtArgs vario_ext_args(int same, const double* iu, int64_t ni, const double* ju, int64_t nj, double qcap,
                                    double cmax, int rank, int world, const double* ib64, const double* jb1024,
-                                   const double* jb256) {
+                                   const double* jbsub) {
     VarioExtArgs a;
     a.same = same;
     a.rank = rank;
@@ -836,7 +836,7 @@ static VarioExtArgs vario_ext_args(int same, const double* iu, int64_t ni, const
     a.nj = nj;
     a.ib = ib64;
     a.jb = jb1024;
-    a.jsb = jb256;
+    a.jsb = jbsub;
     a.qcap = qcap;
     a.cmax = cmax;
     return a;
@@ -844,22 +844,22 @@ static VarioExtArgs vario_ext_args(int same, const double* iu, int64_t ni, const
 
 void ck_launch_vario_extent(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                             int64_t nj, double qcap, void* part, int rank, int world, const double* ib64,
-                            const double* jb1024, const double* jb256, double cmax, unsigned long long* best, double qwin_lo,
+                            const double* jb1024, const double* jbsub, double cmax, unsigned long long* best, double qwin_lo,
                             CkVarioPair* list, unsigned* count, unsigned cap) {
     // best: two 32-bit words of device memory (the first 8 of its 16 bytes), initialised here to "nothing seen yet"
     static const unsigned init[2] = {0x7fffffffu, 0xffffffffu};
     (void)hipMemcpyAsync(best, init, sizeof(init), hipMemcpyHostToDevice, s);
     k_vario_extent<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
-        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jb256), (VarioPartialExt*)part,
+        vario_ext_args(same, iu, ni, ju, nj, qcap, cmax, rank, world, ib64, jb1024, jbsub), (VarioPartialExt*)part,
         (unsigned*)best, qwin_lo, list, count, cap);
 }
 
 void ck_launch_vario_collect(hipStream_t s, int grid, int same, const double* iu, int64_t ni, const double* ju,
                              int64_t nj, double qtop_lo, double qcap, double qbot_hi, CkVarioPair* list, unsigned* count,
                              unsigned cap, int rank, int world, const double* ib64, const double* jb1024,
-                             const double* jb256) {
+                             const double* jbsub) {
     k_vario_collect<<<dim3(grid), dim3(VG_TPB), 0, s>>>(
-        vario_ext_args(same, iu, ni, ju, nj, qcap, 0.0, rank, world, ib64, jb1024, jb256), qtop_lo, qbot_hi, list, count, cap);
+        vario_ext_args(same, iu, ni, ju, nj, qcap, 0.0, rank, world, ib64, jb1024, jbsub), qtop_lo, qbot_hi, list, count, cap);
 }
 
 // bounding balls of blocks of `blk` consecutive points: 4 x ceil(n / blk) doubles
@@ -873,7 +873,7 @@ void ck_launch_vario_bounds(hipStream_t s, const double* u, int64_t n, int blk, 
 void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, const double* iu, const double* iv,
                          int64_t ni, const double* ju, const double* jv, int64_t nj, int nlev, const double* xa,
                          const double* xb, const double* dthr, double cmax, const double* ib64, const double* jb1024,
-                         const double* jb256, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
+                         const double* jbsub, int grid, double* part_sum, unsigned long long* part_cnt, CkVarioPair* list,
                          unsigned* count, unsigned cap, int rank, int world, int nb, double* sums, long long* counts,
                          void* args_dev) {
     VarioBinArgs a;
@@ -897,7 +897,7 @@ void ck_launch_vario_bin(hipStream_t s, int metric, int same, int covariogram, c
     a.cmax = cmax;
     a.ib = ib64;
     a.jb = jb1024;
-    a.jsb = jb256;
+    a.jsb = jbsub;
     a.part_sum = part_sum;
     a.part_cnt = part_cnt;
     a.list = list;
