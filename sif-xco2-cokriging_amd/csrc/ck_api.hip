@@ -1871,11 +1871,11 @@ extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double
         if (vario_upload(h, coords_j, resid_j, n_j, &h->vg_ju, &h->vg_jv, h->vg_cj, h->vg_vj)) return -1;
     }
     HIPCHK(hipMalloc((void**)&h->vg_ib64, (size_t)(4 * ck_vario_nblocks(h->vg_ni, 64) * 8)));
-    HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, 1024) * 8)));
+    HIPCHK(hipMalloc((void**)&h->vg_jb, (size_t)(4 * ck_vario_nblocks(h->vg_nj, CK_VG_JCHUNK) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_jbsub, (size_t)(4 * ck_vario_nblocks(h->vg_nj, CK_VG_JSUB) * 8)));
     HIPCHK(hipMalloc((void**)&h->vg_best, 16));
     ck_launch_vario_bounds(h->stream, h->vg_iu, h->vg_ni, 64, h->vg_ib64);
-    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, 1024, h->vg_jb);
+    ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, CK_VG_JCHUNK, h->vg_jb);
     ck_launch_vario_bounds(h->stream, h->vg_ju, h->vg_nj, CK_VG_JSUB, h->vg_jbsub);
     HIPCHK(hipGetLastError());
     h->vg_bgrid = ck_vario_bin_grid(h->vg_ni, h->vg_nj);

@@ -115,6 +115,9 @@ int ck_launch_mfma_peak(hipStream_t s, int blocks, int waves_per_simd, int iters
                          // balls).  Bin pass at 1 M soundings: 64 -> 85.5 ms, 128 -> 80.9, 256 -> 87.1, 512 -> 122.5 (smaller blocks,
                          // narrower windows, more set-up); at 4 M soundings 128 and 256 are within 2 %
 #endif
+#ifndef CK_VG_JCHUNK
+#define CK_VG_JCHUNK 1024   // "j" points of a wave's pair tile: the unit of the first culling test and of the tile -> wave deal
+#endif
 #define CK_VG_MAXBINS 60   // levels sit one per lane of a wave (ck_vario.hip); a few lanes of slack for the windows
 struct CkVarioExt {
     double rmin, rmax;

@@ -41,7 +41,7 @@
 #include <utility>
 
 #define VG_TPB 256
-#define VG_JCHUNK 1024   // "j" points of a pair tile
+#define VG_JCHUNK CK_VG_JCHUNK   // "j" points of a pair tile
 #define VG_JSUB CK_VG_JSUB   // sub-chunk: unit of the level-window decision of the binning pass
 #define VG_IW 64         // "i" points of a wave tile (binning pass)
 #define VG_MAXBINS CK_VG_MAXBINS
