@@ -43,7 +43,11 @@ def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cokrige.h"))
-    objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp")
+    # experimental builds: one object directory per set of extra definitions (objects are only rebuilt when a SOURCE is
+    # newer, so objects compiled with other -D flags must not be picked up)
+    defs = os.environ.get("CK_BUILD_DEFS", "")
+    tag = "" if not defs else "_" + "".join(ch if ch.isalnum() else "_" for ch in defs)
+    objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp" + tag)
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"] + os.environ.get("CK_BUILD_DEFS", "").split()
     flags += os.environ.get("CK_EXTRA_HIPCC_FLAGS", "").split()   # kernel experiments (-D...); use with --force
