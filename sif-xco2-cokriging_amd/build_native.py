@@ -49,6 +49,7 @@ def build(force=False, verbose=False):
     tag = "" if not defs else "_" + "".join(ch if ch.isalnum() else "_" for ch in defs)
     objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp" + tag)
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed"] + os.environ.get("CK_BUILD_DEFS", "").split()
     flags += os.environ.get("CK_EXTRA_HIPCC_FLAGS", "").split()   # kernel experiments (-D...); use with --force
 

@@ -45,7 +45,12 @@
 #define VG_JSUB CK_VG_JSUB   // sub-chunk: unit of the level-window decision of the binning pass
 #define VG_IW 64         // "i" points of a wave tile (binning pass)
 #define VG_MAXBINS CK_VG_MAXBINS
+#ifndef VG_SLOTS
 #define VG_SLOTS 6       // slot 0: base level (passed by every pair of the sub-chunk); slots 1..5 compared
+#endif
+#ifndef VG_WAVES
+#define VG_WAVES 5       // waves per SIMD asked of the register allocator for k_vario_bin
+#endif
 
 struct VarioPartialExt {
     double rmin, rmax;
@@ -646,7 +651,7 @@ __device__ __forceinline__ void vario_subchunk(vg_args_ptr a, vg_cptr ju0, vg_cp
 // (five waves per SIMD asked for: left alone the register allocator takes 101 VGPRs, four waves, 100 ms instead of 87;
 // at six -- 80 VGPRs, a few spills -- nothing is gained, the vector ALU is the limit by then)
 template <int METRIC, int COV>
-__global__ __launch_bounds__(VG_TPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_vario_bin(
+__global__ __launch_bounds__(VG_TPB) __attribute__((amdgpu_waves_per_eu(VG_WAVES, 8))) void k_vario_bin(
     const VarioBinArgs* __restrict__ args) {
     const vg_args_ptr a = (vg_args_ptr)(uintptr_t)args;
     __shared__ double hsum[VG_TPB / 64][VG_MAXBINS];
