@@ -106,7 +106,11 @@ def cpu_baseline(N_full, m_full):
                  (N_full + m_full) / (N + m)) ** 3}
     ext = {k: st[k] * scale[k] for k in st}
     ext_core = sum(ext[k] for k in core)
-    return {"value": m / dt, "unit": "grid-points/s", "cores": os.cpu_count(), "kind": "port",
+    # `value` is the rate on the SAMPLE (300 x less work than the configuration the GPU ran); `value_at_config` is the
+    # like-for-like figure at the bench's own size -- an extrapolation by operation count (labelled below)
+    return {"value": m / dt, "unit": "grid-points/s", "value_at_config": m_full / ext_core,
+            "value_at_config_is": f"EXTRAPOLATED from the sample by operation count to N={N_full}, m={m_full} (see extrapolation)",
+            "cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle stages of joint Predictor.__call__, n_obs={n}/process (N={N}), m={m} grid points, "
                       f"{dt:.1f} s for the output-producing stages (+ {st['pred_cov_diagnostic_s'] + st['verify_model_diagnostic_s']:.1f} s "
                       f"diagnostics); numpy/scipy, BLAS threads = all {os.cpu_count()} host cores, covariance assembly single-threaded as in the reference",
@@ -118,18 +122,19 @@ def cpu_baseline(N_full, m_full):
 
 
 def measured_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this round
-    (profiles/r02_traffic.json; scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
+    """(bytes per launch, source) -- HBM-side bytes per launch of the dominant kernel from the newest committed PMC passes
+    (profiles/rNN_traffic.json; scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
     runs of this very command, KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
-    streams).  A committed measurement of the same workload, not a live counter: null if absent."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    streams).  A committed measurement of the same workload, NOT a live counter of this run -- `traffic_source` in the
+    bench line says which file it came from; (None, None) if absent."""
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
-                return json.load(open(p)).get("k_syrk_group_bytes_per_launch")
+                return json.load(open(p)).get("k_syrk_group_bytes_per_launch"), f"profiles/{name} (committed rocprofv3 --pmc pass of this command, not a live counter of this run)"
             except Exception:
-                return None
-    return None
+                return None, None
+    return None, None
 
 
 def self_launch(args):
@@ -311,24 +316,38 @@ def main():
             tl = tim[-1]
             flops = trailing_update_flops(N)
             syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
+            # the PMC passes are of the headline workload only
+            traffic, traffic_source = measured_traffic() if (args.config == 2 and n == 20000) else (None, None)
             out["roofline"] = {
                 "kernel": "k_syrk_group_d (Cholesky trailing update over 3-panel groups, v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging)",
                 "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                "traffic": measured_traffic() if (args.config == 2 and n == 20000) else None,   # the PMC passes are of the headline workload
+                "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
                 "algorithmic_flops_per_step": flops,
             }
             aux_s = np.mean([t["aux_gemm_ms"] for t in tim]) / 1e3
             cov_bytes = 8.0 * (N * (N + 1) / 2)
+            # covariance assembly = K1 (Sigma, lower triangle) + K2 (c0^T rows), algorithmic bytes
+            # 8 [N (N + 1) / 2 + N m]; stage timers = HIP events around the device work of each (mean over the timed steps)
+            k1_ms = float(np.mean([t["assemble_sigma_ms"] for t in tim]))
+            k2_ms = float(np.mean([t["assemble_aux_ms"] for t in tim]))
+            k2_bytes = 8.0 * N * m
+
+            def hbm(b, ms):
+                return {"GB": b / 1e9, "ms": ms, "GBs": b / (ms / 1e3) / 1e9, "frac_of_hbm_peak": b / (ms / 1e3) / 1e9 / PEAK_HBM_GBS}
+            cov_assembly = {"K1_sigma": hbm(cov_bytes, k1_ms), "K2_c0": hbm(k2_bytes, k2_ms),
+                            "combined": hbm(cov_bytes + k2_bytes, k1_ms + k2_ms),
+                            "definition": "SURVEY 8(d): 8 [N (N + 1) / 2 + N m] algorithmic bytes over K1 + K2"}
             out["stages"] = {
                 "assemble_sigma_ms": tl["assemble_sigma_ms"], "factor_ms": tl["factor_ms"],
                 "assemble_c0_ms": tl["assemble_aux_ms"], "solve_ms": tl["solve_ms"], "reduce_ms": tl["reduce_ms"],
                 "cholesky_tflops": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12,
                 "cholesky_frac_of_mfma_peak": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                 "solve_gemm_tflops": aux_update_flops(N, m) / aux_s / 1e12 if aux_s > 0 else None,
-                "cov_assembly_GBs": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9,
-                "cov_assembly_frac_of_hbm_peak": cov_bytes / (tl["assemble_sigma_ms"] / 1e3) / 1e9 / PEAK_HBM_GBS,
+                "cov_assembly": cov_assembly,
+                "cov_assembly_GBs": cov_assembly["combined"]["GBs"],
+                "cov_assembly_frac_of_hbm_peak": cov_assembly["combined"]["frac_of_hbm_peak"],
                 # 14 FP64 operations per tabulated entry (3 sub, mul, 2 fma: squared chord;
                 # sub: offset from the interval centre; 7 fma: Horner) against the 78.6 TF vector peak
                 "cov_assembly_frac_of_fp64_valu_peak": 14.0 * (N * (N + 1) / 2) / (tl["assemble_sigma_ms"] / 1e3) / 1e12

@@ -114,8 +114,13 @@ int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, doubl
  * prediction sites of the LAST ck_predict positive definite?  Sigma is (ck_factor succeeded), so this is the
  * Cholesky of the m x m Schur complement C_pp - V^T V on the solved right-hand sides that ck_predict left on the
  * device (the reference factorises the (m + N) x (m + N) matrix).  info = 0: positive definite; > 0: LAPACK-style
- * index of the failing leading minor among the prediction sites (library order) -- the reference then warns
- * "Prediction joint covariance matrix is not positive definte".  Needs m (m + 512) / 2 more doubles of device memory. */
+ * index of the failing leading minor among the prediction sites -- the reference then warns
+ * "Prediction joint covariance matrix is not positive definte".  The index counts the sites in the order the library
+ * laid them out (for m >= 256 with option site_order = 1 that is a Hilbert-curve order, not the caller's): use it as
+ * a verdict (zero / non-zero), as the reference does.  Only valid directly after the ck_predict whose sites are meant:
+ * ck_set_model, ck_set_metric, ck_assemble_joint and ck_factor invalidate the solved right-hand sides and this call then
+ * fails.  Consumes the data row of the right-hand sides (a second call gives the same verdict; ck_aux_finish must
+ * not be repeated after it).  Needs m (m + 512) / 2 more doubles of device memory. */
 int ck_verify_model(ck_handle* h, int64_t* info);
 
 /* Leave-one-out cross-validation of process i at all its data sites from ONE factorisation

@@ -1,4 +1,5 @@
-"""assembly time of Sigma at the headline size, several repetitions in one process (HIP events inside the library)"""
+"""assembly time of Sigma (K1) and of the right-hand-side rows c0^T | z^T (K2) at the headline size, several repetitions in
+one process (HIP events inside the library); SURVEY 8(d): algorithmic bytes 8 [N (N + 1) / 2 + N m] over K1 + K2"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,9 +12,16 @@ h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
 h.set_metric(0)
 for k in range(2):
     h.set_data(k, pb["coords"][k], pb["values"][k])
-ts = []
+ts, ta = [], []
 for it in range(12):
     h.assemble_joint()
     ts.append(h.timings()["assemble_sigma_ms"])
-N = 2 * n
-print("assemble_sigma_ms", " ".join(f"{t:.3f}" for t in ts), "| median", f"{np.median(ts[2:]):.3f}", "ms ->", f"{8 * N * (N + 1) / 2 / np.median(ts[2:]) / 1e9:.2f} TB/s")
+    h.aux_begin(0, pb["pcoords"])
+    ta.append(h.timings()["assemble_aux_ms"])
+N, m = 2 * n, len(pb["pcoords"])
+t1, t2 = np.median(ts[2:]), np.median(ta[2:])
+b1, b2 = 8 * N * (N + 1) / 2, 8 * N * m
+print("assemble_sigma_ms", " ".join(f"{t:.3f}" for t in ts), "| median", f"{t1:.3f}", "ms ->", f"{b1 / t1 / 1e9:.2f} TB/s")
+print("assemble_aux_ms  ", " ".join(f"{t:.3f}" for t in ta), "| median", f"{t2:.3f}", "ms ->", f"{b2 / t2 / 1e9:.2f} TB/s",
+      "(the interval includes the upload of the prediction coordinates and k_prep_sites)")
+print(f"K1 + K2: {(b1 + b2) / 1e9:.2f} GB in {t1 + t2:.3f} ms -> {(b1 + b2) / (t1 + t2) / 1e9:.2f} TB/s = {(b1 + b2) / (t1 + t2) / 1e9 / 8:.3f} of 8 TB/s")

@@ -45,7 +45,11 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cokrige.h"))
     # experimental builds: one object directory per set of extra definitions (objects are only rebuilt when a SOURCE is
     # newer, so objects compiled with other -D flags must not be picked up)
-    defs = os.environ.get("CK_BUILD_DEFS", "")
+    defs = os.environ.get("CK_BUILD_DEFS", "") + " " + os.environ.get("CK_EXTRA_HIPCC_FLAGS", "")
+    defs = defs.strip()
+    if defs and not os.environ.get("CK_BUILD_OUT"):
+        # experimental -D flags must never reach the product library (stale objects in build/ would be mixed with them)
+        raise RuntimeError("CK_BUILD_DEFS / CK_EXTRA_HIPCC_FLAGS need CK_BUILD_OUT=<path of the experimental library>")
     tag = "" if not defs else "_" + "".join(ch if ch.isalnum() else "_" for ch in defs)
     objdir = os.path.join(HERE, "build" if not os.environ.get("CK_BUILD_OUT") else "build_exp" + tag)
     os.makedirs(objdir, exist_ok=True)

@@ -322,6 +322,7 @@ extern "C" int ck_set_model(ck_handle* h, int n_procs, const double* sigma, cons
     HIPCHK(hipStreamSynchronize(h->stream));
     h->model_set = true;
     h->assembled = h->factored = false;
+    h->aux_state = 0;   // solved right-hand sides of the old model must not feed ck_verify_model
     return 0;
 }
 
@@ -332,6 +333,7 @@ extern "C" int ck_set_metric(ck_handle* h, int metric) {
         h->metric = metric;
         h->layout_ready = false;   // site transforms depend on the metric
         h->assembled = h->factored = false;
+        h->aux_state = 0;
     }
     return 0;
 }
@@ -817,6 +819,7 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
     h->t_ms[0] = ms;
     h->assembled = true;
     h->factored = false;
+    h->aux_state = 0;   // right-hand sides solved with the previous factor are stale from here on
     return 0;
 }
 
@@ -1142,6 +1145,7 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     if (h->world != 1) return fail("ck_factor is the single-process form; drive ck_panel_* for world > 1");
     if (!h->assembled) return fail("ck_assemble_joint has not been called");
     if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
+    h->aux_state = 0;
     if (factor_sweep(h)) return -1;
     if (ck_factor_info(h, info)) return -1;
     if (*info != 0 && h->site_order) {
@@ -1201,6 +1205,7 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
         h->p_sorted = false;
         return 0;
     }
+    bool fast_done = false;
     h->p_sorted = may_sort && h->site_order && m >= 256;
     if (h->p_sorted) {
         double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
@@ -1213,9 +1218,11 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
         }
         pcoords = sorted.data();   // alive until the event synchronisation at the end of this function
     }
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
     HIPCHK(hipMemsetAsync(h->d_pcoords, 0, 2 * mpad * 8, h->stream));
     if (m > 0) HIPCHK(hipMemcpyAsync(h->d_pcoords, pcoords, 2 * m * 8, hipMemcpyHostToDevice, h->stream));
+    // timed like ck_assemble_joint: the device work of K2 (site transform, table kernel, exact pass) -- not the upload of the
+    // prediction coordinates in front of it nor the host round trip for the worklist count behind it
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
     ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
@@ -1225,14 +1232,18 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, true, h->d_blk, h->metric, i, h->p0, mpad, h->s0, layout_of(h), h->wl,
                                h->d_sigptr, h->aux);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
         unsigned cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, h->wl.count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->fallback_total += cnt;
-        if (cnt <= h->wl.cap) break;
+        if (cnt <= h->wl.cap) {
+            fast_done = true;
+            break;
+        }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (!fast_done) HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));   // pcoords is caller memory: do not return before the copy is done
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));

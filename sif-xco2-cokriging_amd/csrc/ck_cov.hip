@@ -113,10 +113,17 @@ __device__ __noinline__ void worklist_append(const CkWorklist& wl, unsigned mask
 //
 // Interior sub-tiles (no padding row or column; all but a few per panel), table path only.
 // ru*: the chord vectors of this thread's four rows.
+// ZROWS (right-hand sides, the one row tile per block column that holds row m): rows with 16 a >= zrel are not
+// prediction sites -- row m (16 a == zrel) carries the data values z, the rows behind it zeros; they are computed
+// like any other row (their coordinates are zero padding, finite) and replaced in front of the store, so that
+// this tile runs the same code as the interior ones instead of the entry-by-entry edge path (which made these
+// 79 tiles the tail of the launch).
+template <bool ZROWS>
 __device__ __forceinline__ unsigned assemble_subtile_interior(const double* lcoef, int tbase, unsigned tn,
                                                               const double (&ru0)[4], const double (&ru1)[4],
                                                               const double (&ru2)[4], const CkSiteRef& S, long ct,
-                                                              double* __restrict__ obase, int ty, int tx) {
+                                                              double* __restrict__ obase, int ty, int tx,
+                                                              int zrel = 0, const double* __restrict__ z = nullptr) {
     unsigned slowmask = 0;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -139,7 +146,8 @@ __device__ __forceinline__ unsigned assemble_subtile_interior(const double* lcoe
                 const double q = dx * dx + dy * dy + dz * dz;
                 int iv;
                 y[j] = ck_table_y(q, &iv, tbase);
-                const bool slow = (unsigned)iv >= tn;            // q == 0 (and with it the nugget) lands here
+                bool slow = (unsigned)iv >= tn;                  // q == 0 (and with it the nugget) lands here
+                if (ZROWS) slow = slow && 16 * a < zrel;         // the z row and the zero rows never go to the exact pass
                 slowmask |= slow ? (1u << ((b * 4 + a) * 2 + e)) : 0u;
                 lp[j] = lcoef + min(max(iv, 0), (int)tn - 1);    // keep the lookup inside the table
             }
@@ -161,6 +169,11 @@ __device__ __forceinline__ unsigned assemble_subtile_interior(const double* lcoe
                 d2_t v;
                 v[0] = p[2 * h2];
                 v[1] = p[2 * h2 + 1];
+                if (ZROWS && 16 * (2 * ap + h2) >= zrel) {
+                    const d2_t zv = *reinterpret_cast<const d2_t*>(z + c);
+                    const d2_t zero = {0.0, 0.0};
+                    v = (16 * (2 * ap + h2) == zrel) ? zv : zero;
+                }
                 // non-temporal: 6.4 GB of panels stream out and are next read by the factorisation, long after they
                 // have left every cache (measured -3 % on the kernel against plain stores)
                 __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(obase + (ty + 16 * (2 * ap + h2)) * CK_NB + 2 * tx + 32 * b));
@@ -239,23 +252,28 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
     long row0, col0;
     double* out;
     long tile;
-    if (AUX) {   // every panel has mpad / 64 row tiles
-        const long j = blockIdx.x / pm.aux_tiles;
-        tile = blockIdx.x - j * pm.aux_tiles;
+    if (AUX) {   // every panel has mpad / 64 row tiles; row-tile-major, LAST row tile first: the tiles that hold the z row
+                 // (and, with padding rows behind them, take the edge path) are dispatched first instead of forming the tail
+        const long tr = blockIdx.x / pm.n_panels;
+        const long j = blockIdx.x - tr * pm.n_panels;
+        tile = pm.aux_tiles - 1 - tr;
         row0 = 0;
         col0 = j * CK_NB;
         out = pm.aux + j * pm.aux_tiles * 64 * CK_NB;
-    } else {     // owned panels, sizes differ: tile0[j] = first tile of the j-th owned panel
+    } else {     // owned panels, sizes differ: tile0[j] = first tile of the j-th owned panel.  Dispatched back to front: the
+                 // last panels are short and mostly padding (edge path), the launch should not end on them
+        const int bid = (int)(gridDim.x - 1 - blockIdx.x);
         int j = 0;
-        while (j + 1 < pm.n_panels && pm.tile0[j + 1] <= (int)blockIdx.x) ++j;
+        while (j + 1 < pm.n_panels && pm.tile0[j + 1] <= bid) ++j;
         const int K = pm.panel_of[j];
-        tile = blockIdx.x - pm.tile0[j];
+        tile = bid - pm.tile0[j];
         row0 = col0 = (long)K * CK_NB;
         out = pm.sigptr[K];
     }
     const long rt = row0 + tile * 64;
     const int pr = AUX ? i_pred : (int)(rt >= L.n0p);
     const bool row_pad = AUX ? (rt + 64 > m) : range_has_padding(L, rt);
+    const int zrel = AUX ? (int)(m - rt) - ty : 0;   // this thread's row a is r = m + (16 a - zrel)
     double ru0[4], ru1[4], ru2[4];   // table path: chord vectors of this thread's four rows
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -283,10 +301,14 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
             loaded = bidx;
         }
         unsigned slowmask;
-        if (!FAST || row_pad || range_has_padding(L, ct))
+        // right-hand sides: the row tile that holds row m runs the interior code with its rows >= m replaced in front of the
+        // store (ZROWS; thread row a is row m + (16 a - zrel))
+        if (!FAST || (row_pad && !AUX) || range_has_padding(L, ct))
             slowmask = assemble_subtile_edge<FAST, AUX>(mb, metric, lcoef, tbase, tn, R, S, z, L, rt, ct, m, nug, obase, ty, tx);
+        else if (AUX && row_pad)
+            slowmask = assemble_subtile_interior<true>(lcoef, tbase, tn, ru0, ru1, ru2, S, ct, obase, ty, tx, zrel, z);
         else
-            slowmask = assemble_subtile_interior(lcoef, tbase, tn, ru0, ru1, ru2, S, ct, obase, ty, tx);
+            slowmask = assemble_subtile_interior<false>(lcoef, tbase, tn, ru0, ru1, ru2, S, ct, obase, ty, tx);
         if (FAST && __builtin_amdgcn_ballot_w64(slowmask != 0u) != 0ULL)   // rare: hand the pairs to the exact pass
             worklist_append(wl, slowmask, (int)(rt + ty), 16, (int)(ct + 2 * tx));
     }
