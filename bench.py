@@ -228,10 +228,17 @@ def main():
             return h.predict(0, pb["pcoords"])
     else:
         from sif_xco2_cokriging_amd import distributed
+        # CK_PANEL_EXCHANGE = broadcast | sag | p2p | auto (default: one mid-size panel through each at warm-up, the
+        # fastest is kept); CK_PANEL_GROUP = 1 | 2 | 3 ... | auto (default: one pass of the per-panel schedule against one
+        # of the grouped one at warm-up) -- nothing about the multi-GPU form is chosen untimed
+        pg = os.environ.get("CK_PANEL_GROUP", "auto")
         runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank),
-                                              exchange=os.environ.get("CK_PANEL_EXCHANGE", "broadcast"))
+                                              exchange=os.environ.get("CK_PANEL_EXCHANGE", "auto"),
+                                              panel_group=pg if pg == "auto" else int(pg))
         runner.prepare(m_total=m)
         h.set_option("time_gemm", 2)   # HIP events around this rank's Sigma trailing-update launches
+        runner.calibrate()
+        runner.autotune(0, pb["pcoords"])   # untimed calibration passes, in front of the W warm-up steps
 
         def step():
             return runner.predict(0, pb["pcoords"])
@@ -292,8 +299,11 @@ def main():
         if per_rank is not None:
             nK = -(-N // 512)
             out["per_rank"] = per_rank
-            out["comm"] = {"collective": ("panel scatter + point-to-point all-gather (CK_PANEL_EXCHANGE=p2p)" if runner.exchange == "p2p" and world > 2
-                                          else "panel broadcast (RCCL over xGMI)") + ", one per 512-column panel, look-ahead depth 1",
+            names = {"broadcast": "panel broadcast", "sag": "panel scatter + in-place all-gather (two collectives)",
+                     "p2p": "panel scatter + point-to-point all-gather (batch_isend_irecv)"}
+            out["comm"] = {"collective": names.get(runner.exchange, runner.exchange) + f" over {backend}, one per 512-column panel, look-ahead kept",
+                           "exchange": runner.exchange, "exchange_calibration": runner.comm_info,
+                           "panel_group": runner.G, "panel_group_tuning": runner.tune_info,
                            "panels": nK, "bytes_received_per_rank_per_step": int(sum((nK * 512 - K * 512) * 512 * 8 + 8 * 64 * 64 * 8
                                                                                      for K in range(nK) if K % world != 0)),
                            "note": "bcast_wait_ms = time the rank's stream waited for a panel after its own updates were done "

@@ -42,6 +42,10 @@ typedef struct ck_handle ck_handle;
 
 #define CK_APPLY_SIGMA 1 /* ck_panel_apply: update the local trailing block columns of Sigma */
 #define CK_APPLY_AUX 2   /* ck_panel_apply: forward-substitute / update the right-hand-side rows */
+/* Every panel buffer (ck_panel_buffer: the owner's storage or a receive slot) is followed by this many bytes the
+ * library never reads or writes: room for the host to pad a panel to a multiple of world x 4 KB, so that the exchange
+ * can be an in-place all-gather of equal pieces (distributed.py, exchange = "sag"). */
+#define CK_PANEL_SLACK_BYTES (64 * 512 * 8)
 
 /* ---- library ------------------------------------------------------------- */
 const char* ck_last_error(void);
@@ -152,6 +156,19 @@ int ck_panel_apply(ck_handle* h, int K, int what);
  * K + 1 .. n_panels - 1).  With it the host can run the classical look-ahead: update column K + 1 first,
  * factor it, start its broadcast, and update the remaining columns under the broadcast. */
 int ck_panel_apply_sigma(ck_handle* h, int K, int J_lo, int J_hi);
+/* Grouped form (world >= 1): the panels K0 .. K0 + np - 1 -- all readable on this rank, in their owner's storage or in a
+ * receive slot (remote panel K lands in slot K % recv_slots, option "recv_slots", default 2; at most recv_slots remote
+ * panels are alive at a time) -- applied in ONE pass with the contraction dimension 512 np, i.e. a np-th of the
+ * read-modify-write traffic of np calls of ck_panel_apply (single process: what ck_factor / ck_predict do for groups of 3).
+ *   what & CK_APPLY_SIGMA: the locally owned block columns J of [max(J_lo, K0 + np), J_hi], every n_phase-th of them
+ *                          starting with the phase-th (so that the host can split one group update into n_phase pieces
+ *                          and start the next panels' steps and exchanges in between);
+ *   what & CK_APPLY_AUX:   the update part only (no substitution) of the right-hand-side block columns of the same
+ *                          range, piece `phase` of n_phase contiguous pieces.
+ * ck_panel_aux_solve(K): the substitution of right-hand-side block column K with the diagonal block of panel K
+ * (ck_panel_apply(K, CK_APPLY_AUX) = ck_panel_aux_solve(K) + the update of the block columns beyond K). */
+int ck_panel_apply_group(ck_handle* h, int K0, int np, int what, int J_lo, int J_hi, int phase, int n_phase);
+int ck_panel_aux_solve(ck_handle* h, int K);
 /* pred / pred_err of the local shard after all panels were applied to the aux rows. */
 int ck_aux_finish(ck_handle* h, double* pred_host, double* pred_err_host);
 /* info flag of the factorisation so far (synchronises). */
@@ -242,6 +259,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1/2) brackets every trailing-update launch with HIP events (2: the Sigma updates only, for
  * the step-wise form, where Sigma and right-hand-side updates alternate; read back through ck_timings);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
+ * "recv_slots" (2..64, default 2; before the first assemble / ck_estimate_bytes): receive buffers for remote panels of a
+ * multi-process run -- 2 for the per-panel look-ahead schedule, 2 G for the grouped one (ck_panel_apply_group);
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of

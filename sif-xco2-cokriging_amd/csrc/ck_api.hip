@@ -114,7 +114,10 @@ struct ck_handle {
     double** d_panelptr = nullptr;   // where panel K can be read on this rank: own storage or receive buffer K & 1
     int *d_tile0 = nullptr, *d_panel_of = nullptr;   // assembly launch map of the owned panels
     int n_owned = 0, total_tiles = 0;
-    double* recv[2] = {nullptr, nullptr};   // receive buffers for remote panels (world > 1)
+    // receive slots for remote panels (world > 1): panel K lands in slot K % recv_slots.  Two slots carry the per-panel
+    // look-ahead schedule; 2 G slots the grouped one (the G panels of the group being applied + the G being received)
+    int recv_slots = 2;
+    std::vector<double*> recv;
     long long* d_info = nullptr;
     bool assembled = false, factored = false;
     // aux
@@ -638,7 +641,7 @@ static int ensure_layout(ck_handle* h) {
         h->sig.assign(h->nK, nullptr);
         for (int K = h->rank; K < h->nK; K += h->world) {
             const int64_t rows = Np - (int64_t)K * CK_NB;
-            if (dev_alloc(h, (void**)&h->sig[K], (rows * CK_NB + CK_PANEL_TAIL) * 8)) return -1;
+            if (dev_alloc(h, (void**)&h->sig[K], (rows * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES)) return -1;
         }
         if (dev_alloc(h, (void**)&h->d_sigptr, (int64_t)h->nK * sizeof(double*))) return -1;
         HIPCHK(hipMemcpy(h->d_sigptr, h->sig.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
@@ -657,12 +660,13 @@ static int ensure_layout(ck_handle* h) {
         HIPCHK(hipMemcpy(h->d_tile0, tile0.data(), tile0.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_panel_of, panel_of.data(), panel_of.size() * sizeof(int), hipMemcpyHostToDevice));
         if (h->world > 1) {
-            for (int b = 0; b < 2; ++b)
-                if (dev_alloc(h, (void**)&h->recv[b], (Np * CK_NB + CK_PANEL_TAIL) * 8)) return -1;
+            h->recv.assign((size_t)h->recv_slots, nullptr);
+            for (int b = 0; b < h->recv_slots; ++b)
+                if (dev_alloc(h, (void**)&h->recv[(size_t)b], (Np * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES)) return -1;
         }
         {
             std::vector<double*> pp(h->nK);
-            for (int K = 0; K < h->nK; ++K) pp[K] = h->sig[K] ? h->sig[K] : h->recv[K & 1];
+            for (int K = 0; K < h->nK; ++K) pp[K] = h->sig[K] ? h->sig[K] : (h->world > 1 ? h->recv[(size_t)(K % h->recv_slots)] : nullptr);
             if (dev_alloc(h, (void**)&h->d_panelptr, (int64_t)h->nK * sizeof(double*))) return -1;
             HIPCHK(hipMemcpy(h->d_panelptr, pp.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
         }
@@ -839,7 +843,9 @@ extern "C" int ck_panel_owner(ck_handle* h, int K, int* owner_rank) {
     return 0;
 }
 
-static const double* panel_src(ck_handle* h, int K) { return h->sig[K] ? h->sig[K] : h->recv[K & 1]; }
+static const double* panel_src(ck_handle* h, int K) {
+    return h->sig[K] ? h->sig[K] : (h->recv.empty() ? nullptr : h->recv[(size_t)(K % h->recv_slots)]);
+}
 
 extern "C" int ck_panel_buffer(ck_handle* h, int K, void** dev_ptr, int64_t* nbytes) {
     CHKH(h);
@@ -1028,6 +1034,54 @@ extern "C" int ck_panel_apply_sigma(ck_handle* h, int K, int J_lo, int J_hi) {
     J_hi = std::min(J_hi, h->nK - 1);
     if (J_lo > J_hi) return 0;
     apply_sigma_on(h, K, panel_src(h, K), J_lo, J_hi, h->stream, true);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ck_panel_apply_group(ck_handle* h, int K0, int np, int what, int J_lo, int J_hi, int phase, int n_phase) {
+    CHKH(h);
+    if (K0 < 0 || np < 1 || K0 + np > h->nK) return fail("bad panel group");
+    if (n_phase < 1 || phase < 0 || phase >= n_phase) return fail("bad phase");
+    for (int p = 0; p < np; ++p)
+        if (!panel_src(h, K0 + p)) return fail("panel " + std::to_string(K0 + p) + " is not readable on this rank");
+    if (h->world > 1 && np > h->recv_slots) return fail("panel group larger than recv_slots");
+    J_lo = std::max(J_lo, K0 + np);
+    J_hi = std::min(J_hi, h->nK - 1);
+    if (J_lo > J_hi) return 0;
+    if (what & CK_APPLY_SIGMA) {
+        // the owned block columns of [J_lo, J_hi], every n_phase-th of them starting with the phase-th
+        int J0 = J_lo;
+        while (J0 <= J_hi && (J0 % h->world) != h->rank) ++J0;
+        J0 += phase * h->world;
+        if (J0 <= J_hi) {
+            const int step = h->world * n_phase;
+            const int nJ = (J_hi - J0) / step + 1;
+            gemm_timed_begin(h);
+            ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, np, J0, step, nJ, h->Npad, h->nend);
+            gemm_timed_end(h);
+        }
+    }
+    if ((what & CK_APPLY_AUX) && h->mpad > 0) {
+        // right-hand-side block columns: piece `phase` of n_phase contiguous pieces of [J_lo, J_hi]
+        const int tot = J_hi - J_lo + 1, per = (tot + n_phase - 1) / n_phase;
+        const int a = J_lo + phase * per, b = std::min(J_hi, a + per - 1);
+        if (a <= b) {
+            const bool timed = h->time_gemm == 1;
+            if (timed) gemm_timed_begin(h);
+            ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, np, a, b - a + 1, aux_rows(h, K0 + np - 1), h->nend);
+            if (timed) gemm_timed_end(h);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ck_panel_aux_solve(ck_handle* h, int K) {
+    CHKH(h);
+    if (K < 0 || K >= h->nK) return fail("bad panel index");
+    const double* P = panel_src(h, K);
+    if (!P) return fail("panel " + std::to_string(K) + " is not readable on this rank");
+    if (h->mpad > 0) aux_inner_on(h, K, P, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2249,9 +2303,9 @@ extern "C" int ck_estimate_bytes(ck_handle* h, int64_t m, int64_t* out) {
     const int nK = (int)(Np / CK_NB);
     auto al = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
     int64_t tot = 2 * al(3 * Np * 8) + al(Np * 8);
-    for (int K = h->rank; K < nK; K += h->world) tot += al(((Np - (int64_t)K * CK_NB) * CK_NB + CK_PANEL_TAIL) * 8);
+    for (int K = h->rank; K < nK; K += h->world) tot += al(((Np - (int64_t)K * CK_NB) * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES);
     tot += 2 * al((int64_t)nK * sizeof(double*));   // d_sigptr, d_panelptr
-    if (h->world > 1) tot += 2 * al((Np * CK_NB + CK_PANEL_TAIL) * 8);
+    if (h->world > 1) tot += (int64_t)h->recv_slots * al((Np * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES);
     const int64_t mpad = roundup(m + 1, CK_AUX_ALIGN);
     tot += al(mpad * Np * 8) + 2 * al(3 * mpad * 8) + 2 * al(2 * mpad * 8);
     *out = tot + 4096;
@@ -2351,6 +2405,12 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
             h->aux_state = 0;
         }
         h->site_order = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "recv_slots")) {   // see ck_handle::recv_slots; before the first assemble / ck_estimate_bytes
+        if (value < 2 || value > 64) return fail("recv_slots must be in [2, 64]");
+        if (h->layout_ready || !h->sig.empty()) return fail("recv_slots must be set before the panels are allocated");
+        h->recv_slots = (int)value;
         return 0;
     }
     if (!strcmp(name, "exact_cov")) {   // 1: per-entry Bessel evaluation instead of the tables

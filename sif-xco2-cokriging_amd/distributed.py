@@ -70,30 +70,61 @@ class _Works:
         return True
 
 
+class _StreamWork:
+    """An exchange that ran on a side stream: wait() makes the CURRENT stream wait for its end (no host block)."""
+
+    def __init__(self, done_event, device):
+        self.done, self.device = done_event, device
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream(self.device).wait_event(self.done)
+        return True
+
+
+EXCHANGES = ("broadcast", "sag", "p2p")
+
+
 class DistributedJoint:
-    """exchange = "broadcast": one collective broadcast per panel (RCCL picks ring / tree: every hop carries the whole
-    panel, so a step costs panel_bytes / one link).  exchange = "p2p": the owner SCATTERS the panel -- piece r to rank r,
-    seven pieces leaving on seven xGMI links at once -- and the ranks then exchange their pieces all-to-all by
-    point-to-point sends (every rank sends its eighth to the six others over its own links): both phases move an
-    eighth of the panel per link, 2 x panel_bytes / 8 per step instead of panel_bytes.  Same bytes land in the same
-    receive buffer; chosen with CK_PANEL_EXCHANGE=p2p (bench.py) until it has been timed on an 8-GPU node."""
+    """One rank of the multi-GPU joint predictor.
+
+    exchange -- how panel K travels from its owner to every rank:
+      "broadcast"  one collective broadcast per panel (RCCL picks ring / tree);
+      "sag"        scatter + in-place all-gather (two RCCL collectives): the owner hands piece r of the panel to rank r,
+                   then all ranks gather the pieces -- every link carries panel_bytes / world per phase;
+      "p2p"        the same data movement spelled as point-to-point sends (batch_isend_irecv): piece r to rank r over the
+                   owner's seven xGMI links at once, then every rank forwards its piece to the others over its own links;
+      "auto"       calibrate(): one mid-size panel through each of them at warm-up, all ranks take the one whose slowest
+                   rank was fastest (timings and choice are kept in `comm_info`).
+    panel_group -- 1: per-panel schedule with look-ahead of depth 1 (two receive slots); G > 1: the trailing updates
+      are applied for G panels at once (K = 512 G, a G-th of the C traffic: _sweep_grouped, 2 G receive slots); "auto":
+      storage for G = 3 and autotune() times one pass of either schedule and keeps the faster."""
 
     def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True,
-                 exchange: str = "broadcast"):
+                 exchange: str = "broadcast", panel_group=1):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
         self.lookahead = bool(lookahead)
-        if exchange not in ("broadcast", "p2p"):
-            raise ValueError("exchange must be 'broadcast' or 'p2p'")
+        if exchange not in EXCHANGES + ("auto",):
+            raise ValueError("exchange must be one of " + ", ".join(EXCHANGES + ("auto",)))
         self.exchange = exchange
+        if panel_group != "auto" and not (isinstance(panel_group, int) and 1 <= panel_group <= 8):
+            raise ValueError("panel_group must be 1..8 or 'auto'")
+        self.panel_group = panel_group
+        self.G = 1 if panel_group == "auto" else int(panel_group)   # the schedule in force
+        self.slots = 2 if panel_group == 1 else 2 * (3 if panel_group == "auto" else int(panel_group))
         self.arena = None
         # this rank's breakdown of the last predict(): panel_ms (panel steps it owned, incl. the look-ahead column
         # update in front of them), update_ms (trailing + right-hand-side updates, collective enqueue), bcast_wait_ms
         # (its stream waiting for a panel after its own updates: exposed communication), assemble_ms, finish_ms
         self.timings = {}
+        self.comm_info = {"exchange": None if exchange == "auto" else exchange, "calibration_ms": None}
+        self.tune_info = {"panel_group": self.G, "pass_ms": None}
         self._marks = _Marks(device)
         self._steps = []
         self._caller_order = False   # set once a not-positive-definite Sigma has been re-swept in the caller's order
+        self._resident = False       # the factor of the last predict() is still in the panels
+        self._xstream = None
 
     # -- setup ------------------------------------------------------------------------------------
     def shard(self, m_total: int):
@@ -108,6 +139,8 @@ class DistributedJoint:
         import torch
         h = self.h
         h.set_partition(self.rank, self.world)
+        if self.world > 1 and self.slots != 2:
+            h.set_option("recv_slots", self.slots)
         _, _, chunk = self.shard(m_total)
         nbytes = h.estimate_bytes(chunk)
         if hasattr(h, "make_arena"):           # CPU stand-in used by the gloo tests
@@ -118,34 +151,94 @@ class DistributedJoint:
             h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         return self
 
-    def _panel_tensor(self, K):
+    def _panel_tensor(self, K, pad_to=0):
+        """Panel K as a float64 tensor; pad_to > 0: lengthened to that many elements into the slack behind every panel
+        buffer (include/cokrige.h: CK_PANEL_SLACK_BYTES)."""
         if hasattr(self.h, "panel_tensor"):
-            return self.h.panel_tensor(K)
+            return self.h.panel_tensor(K, pad_to) if pad_to else self.h.panel_tensor(K)
         import torch
         ptr, nbytes = self.h.panel_buffer(K)
+        if pad_to:
+            assert 0 <= 8 * pad_to - nbytes <= native.PANEL_SLACK_BYTES, "padding beyond the panel's slack"
+            nbytes = 8 * pad_to
         off = ptr - self.arena.data_ptr()
         assert 0 <= off and off + nbytes <= self.arena.numel(), "panel outside the arena"
         return self.arena[off:off + nbytes].view(torch.float64)
 
+    def _piece(self, n):
+        """Length of one of the world equal pieces of an n-element panel (a multiple of 512 elements = 4 KB)."""
+        return -(-(-(-n // self.world)) // 512) * 512
+
     def _pieces(self, n):
         """[lo, hi) of the world pieces of an n-element panel (multiples of 512 elements, the last takes the rest)."""
-        step = -(-(-(-n // self.world)) // 512) * 512
+        step = self._piece(n)
         return [(min(r * step, n), min((r + 1) * step, n)) for r in range(self.world)]
 
-    def _stream_ordered(self):
+    def _backend(self):
         try:
-            return self.dist.get_backend(self.group) == "nccl"
+            return self.dist.get_backend(self.group)
         except Exception:
-            return False
+            return None
 
-    def _exchange(self, K, src, async_op=False):
+    def _on_side_stream(self, fn):
+        """Run fn() -- which enqueues communication and may wait on it -- on a side stream that first waits for everything
+        enqueued on the current stream so far; returns a work whose wait() makes the current stream wait for fn's end.
+        nccl only (stream-ordered works); elsewhere fn() simply runs."""
+        if self._backend() != "nccl" or self.device is None:
+            return _Works(fn() or [])
+        import torch
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._xstream):
+            self._xstream.wait_event(ready)
+            for w in (fn() or []):
+                w.wait()            # stream-ordered: blocks the side stream only
+            done.record(self._xstream)
+        return _StreamWork(done, self.device)
+
+    def _exchange(self, K, src, async_op=False, how=None):
         """Panel K from its owner `src` into every rank's buffer for it."""
-        t = self._panel_tensor(K)
         dist = self.dist
-        if self.exchange == "broadcast" or self.world < 3 or not hasattr(dist, "P2POp"):
+        how = how or self.exchange
+        if how == "auto":
+            how = "broadcast"       # not calibrated (yet)
+        if how == "p2p" and (self.world < 3 or not hasattr(dist, "P2POp")):
+            how = "broadcast"
+        if how == "sag" and (self.world < 2 or not hasattr(dist, "all_gather_into_tensor")):
+            how = "broadcast"
+        if how == "broadcast":
+            t = self._panel_tensor(K)
             return dist.broadcast(t, src=src, group=self.group, async_op=async_op)
-        pc = self._pieces(t.numel())
         me = self.rank
+        if how == "sag":
+            n = self._panel_tensor(K).numel()
+            piece = self._piece(n)
+            tp = self._panel_tensor(K, pad_to=piece * self.world)
+            mine = tp[me * piece:(me + 1) * piece]
+            ordered = self._backend() == "nccl"
+
+            def run():
+                lst = [tp[r * piece:(r + 1) * piece] for r in range(self.world)] if me == src else None
+                w1 = dist.scatter(mine, lst, src=src, group=self.group, async_op=True)
+                if not ordered:
+                    w1.wait()       # gloo: the piece must have arrived before it is gathered
+                    w2 = dist.all_gather_into_tensor(tp, mine.clone(), group=self.group, async_op=True)
+                    return [w2]
+                # RCCL: both collectives run in order on the communicator's stream; in-place gather (input = own slice)
+                w2 = dist.all_gather_into_tensor(tp, mine, group=self.group, async_op=True)
+                return [w1, w2]
+            w = self._on_side_stream(run)
+            if async_op:
+                return w
+            w.wait()
+            return None
+        # "p2p"
+        t = self._panel_tensor(K)
+        pc = self._pieces(t.numel())
         ops1, ops2 = [], []
         if me == src:                                   # phase 1: scatter, piece r -> rank r
             for r in range(self.world):
@@ -166,28 +259,99 @@ class DistributedJoint:
                     ops2.append(dist.P2POp(dist.isend, t[lo:hi], r, self.group))
                 if pc[r][1] > pc[r][0]:
                     ops2.append(dist.P2POp(dist.irecv, t[pc[r][0]:pc[r][1]], r, self.group))
-        works = []
-        if ops1:
-            works += dist.batch_isend_irecv(ops1)
-        if me != src and works and not self._stream_ordered():
-            for w in works:                             # my piece must have arrived before I pass it on (RCCL: both
-                w.wait()                                # batches run in order on the communicator's stream)
-            works = []
-        if ops2:
-            works += dist.batch_isend_irecv(ops2)
-        w = _Works(works)
+
+        def run():
+            works = dist.batch_isend_irecv(ops1) if ops1 else []
+            for w in works:          # my piece must have arrived before I pass it on: explicit, whatever the backend
+                w.wait()             # (on the side stream this blocks neither the host nor the update kernels)
+            return dist.batch_isend_irecv(ops2) if ops2 else []
+        w = self._on_side_stream(run)
         if async_op:
             return w
         w.wait()
         return None
 
+    # -- calibration ------------------------------------------------------------------------------
+    def _reduce_max(self, x):
+        import torch
+        dev = self.device if (self.device is not None and self._backend() == "nccl") else "cpu"
+        t = torch.tensor([float(v) for v in x], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return [float(v) for v in t.cpu().tolist()]
+
+    def _sync(self):
+        if self._marks.cuda:
+            import torch
+            torch.cuda.synchronize(self.device)
+
+    def calibrate(self, reps: int = 2):
+        """exchange = "auto": send one mid-size panel through every exchange this backend offers (one warm-up, `reps`
+        timed repetitions, host clock around device synchronisation), MAX over the ranks of each, and keep the
+        fastest -- every rank computes the same choice from the same reduced numbers.  The panel's content is
+        whatever the buffers hold (call before or between passes, not inside one)."""
+        import time
+        if self.world == 1 or self.exchange != "auto":
+            return self.comm_info
+        nK = self.h.num_panels()[0]
+        K = nK // 2
+        src = K % self.world
+        cands = ["broadcast"]
+        if hasattr(self.dist, "all_gather_into_tensor"):
+            cands.append("sag")
+        if self.world >= 3 and hasattr(self.dist, "P2POp"):
+            cands.append("p2p")
+        ms = []
+        for how in cands:
+            try:
+                self._exchange(K, src, how=how)
+                self._sync()
+                self.dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self._exchange(K, src, how=how)
+                self._sync()
+                ms.append((time.perf_counter() - t0) / reps * 1e3)
+            except Exception:      # an exchange this backend cannot run is simply not a candidate
+                ms.append(float("inf"))
+        ms = self._reduce_max(ms)
+        best = min(range(len(cands)), key=lambda k: ms[k])
+        self.exchange = cands[best]
+        n = self._panel_tensor(K).numel()
+        self.comm_info = {"exchange": self.exchange, "calibration_panel": K, "calibration_bytes": 8 * n,
+                          "calibration_ms": {c: (None if v == float("inf") else round(v, 3)) for c, v in zip(cands, ms)}}
+        return self.comm_info
+
+    def autotune(self, i: int, pcoords):
+        """panel_group = "auto": one full pass with the per-panel schedule, one with the grouped one (G = 3), host clock,
+        MAX over the ranks; keeps the faster.  Returns the result of the last pass."""
+        import time
+        if self.panel_group != "auto":
+            return self.predict(i, pcoords)
+        res, ms = None, []
+        for G in (1, 3):
+            self.G = G
+            self.predict(i, pcoords)        # untimed: first use of a schedule (allocations, clocks)
+            self._sync()
+            if self.world > 1:
+                self.dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            res = self.predict(i, pcoords)
+            self._sync()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        if self.world > 1:
+            ms = self._reduce_max(ms)
+        self.G = 1 if ms[0] <= ms[1] else 3
+        self.tune_info = {"panel_group": self.G, "pass_ms": {"G=1": round(ms[0], 2), "G=3": round(ms[1], 2)}}
+        return res
+
+    # -- schedules ----------------------------------------------------------------------------------
     def _sweep_lookahead(self, nK):
         """Factor / broadcast / apply with the next panel's factorisation and transfer under the
         current panel's update.  The collective is enqueued BEFORE the big update kernels, so its
         kernel holds its few CUs before they fill the chip; it reads panel K + 1 and writes the
-        receive buffer (K + 1) & 1, the update reads panel K (buffer K & 1) and writes columns
+        receive buffer (K + 1) % slots, the update reads panel K (buffer K % slots) and writes columns
         beyond K + 1 -- disjoint."""
-        h, dist, mk = self.h, self.dist, self._marks.mark
+        h, mk = self.h, self._marks.mark
         t0 = mk()
         if self.rank == 0:
             h.panel_factor(0)
@@ -212,11 +376,90 @@ class DistributedJoint:
                 work.wait()
             self._steps.append((t0, t1, t2, mk()))
 
+    def _sweep_grouped(self, nK, G):
+        """Trailing updates for G panels at once (contraction dimension 512 G: a G-th of the read-modify-write traffic
+        of the per-panel schedule), with the look-ahead kept: while the group K0 .. K0 + G - 1 is resident on every
+        rank, the NEXT group's panels are factored one after the other -- their owners update their block column first
+        (by the resident group, then by the panels of the next group that have already arrived), factor it and start
+        its exchange -- and between those steps every rank applies one of G pieces of the resident group's update to
+        the rest of its block columns and right-hand-side rows.  2 G receive slots: G panels in use, G arriving."""
+        h, mk, world, me = self.h, self._marks.mark, self.world, self.rank
+        SIG, AUX = native.APPLY_SIGMA, native.APPLY_AUX
+        works = {}
+
+        def need(K):            # panel K must have arrived before a kernel that reads it is enqueued
+            w = works.pop(K, None)
+            if w is not None:
+                w.wait()
+
+        def chain(N0, Gn, K0, Gc):
+            """panels N0 .. N0 + Gn - 1; between them the pieces of the update by the resident group K0 .. K0 + Gc - 1"""
+            for g in range(Gn):
+                J = N0 + g
+                t0 = mk()
+                if J % world == me:
+                    if g > 0:
+                        for q in range(N0, J):
+                            need(q)
+                        h.panel_apply_group(N0, g, SIG, J, J)
+                    h.panel_factor(J)
+                t1 = mk()
+                if world > 1:
+                    works[J] = self._exchange(J, J % world, async_op=True)
+                if Gc > 0:
+                    h.panel_apply_group(K0, Gc, SIG, N0 + Gn, nK - 1, g, Gn)
+                    h.panel_apply_group(K0, Gc, AUX, N0, nK - 1, g, Gn)
+                t2 = mk()
+                self._steps.append((t0, t1, t2, t2))
+
+        chain(0, min(G, nK), 0, 0)          # the first group has nothing to hide under
+        K0 = 0
+        while K0 < nK:
+            Gc = min(G, nK - K0)
+            N0 = K0 + Gc
+            Gn = min(G, nK - N0)
+            t0 = mk()
+            for q in range(K0, N0):
+                need(q)
+            t1 = mk()
+            self._steps.append((t0, t0, t0, t1))           # exposed communication: the stream waited here
+            t0 = mk()
+            for g in range(Gc):             # right-hand sides through the resident group (local work only)
+                if g > 0:
+                    h.panel_apply_group(K0, g, AUX, K0 + g, K0 + g)
+                h.panel_aux_solve(K0 + g)
+            if Gn > 0:                      # this rank's block columns of the next group come first
+                h.panel_apply_group(K0, Gc, SIG, N0, N0 + Gn - 1)
+            t1 = mk()
+            self._steps.append((t0, t0, t1, t1))
+            if Gn > 0:
+                chain(N0, Gn, K0, Gc)
+            K0 = N0
+        for q in list(works):
+            need(q)
+
+    def _sweep_solve_only(self, nK):
+        """The factor is resident (panel K in its owner's storage): every rank needs each panel once more for its own
+        right-hand-side rows -- exchange of panel K + 1 under the substitution with panel K."""
+        h, mk = self.h, self._marks.mark
+        work = self._exchange(0, 0, async_op=True) if self.world > 1 else None
+        for K in range(nK):
+            t0 = mk()
+            if work is not None:
+                work.wait()
+            t1 = mk()
+            nxt = K + 1
+            work = self._exchange(nxt, nxt % self.world, async_op=True) if (self.world > 1 and nxt < nK) else None
+            h.panel_apply(K, native.APPLY_AUX)
+            t2 = mk()
+            self._steps.append((t0, t0, t2, t2, t0, t1))
+
     # -- one pass of the hot path ---------------------------------------------------------------------
-    def predict(self, i: int, pcoords):
-        """assemble -> (factor + broadcast + apply) per panel -> reduce; returns the full-length
+    def predict(self, i: int, pcoords, reuse_factor: bool = False):
+        """assemble -> (factor + exchange + apply) per panel -> reduce; returns the full-length
         (pred, pred_err) on every rank.  Raises numpy.linalg.LinAlgError like scipy's cho_factor
-        when Sigma is not positive definite."""
+        when Sigma is not positive definite.  reuse_factor: the factor of the previous predict() is still resident
+        (same model, same data) -- only the right-hand sides are assembled and swept."""
         import torch
         h, dist = self.h, self.dist
         pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
@@ -224,12 +467,19 @@ class DistributedJoint:
         lo, hi, chunk = self.shard(m)
         mk = self._marks.mark
         self._steps = []
+        solve_only = bool(reuse_factor and self._resident)
+        self._resident = False
         ta = mk()
-        h.assemble_joint()
+        if not solve_only:
+            h.assemble_joint()
         h.aux_begin(i, pc[lo:hi])
         tb = mk()
         nK, _, _ = h.num_panels()
-        if self.world > 1 and self.lookahead:
+        if solve_only:
+            self._sweep_solve_only(nK)
+        elif self.G > 1:
+            self._sweep_grouped(nK, self.G)
+        elif self.world > 1 and self.lookahead:
             self._sweep_lookahead(nK)
         else:
             for K in range(nK):
@@ -286,6 +536,7 @@ class DistributedJoint:
                 return self.predict(i, pcoords)
             from numpy.linalg import LinAlgError
             raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
+        self._resident = True
         return pred, err
 
 
@@ -350,21 +601,32 @@ class DistributedLocal:
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
 
-    def predict(self, i: int, pcoords, max_dist: float = 1e3, cv: bool = False):
+    def predict(self, i: int, pcoords, max_dist: float = 1e3, cv: bool = False, with_info: bool = False):
+        """(pred, pred_err) of all points on every rank; with_info: also the counters of ck_predict_local summed
+        (n_empty, n_not_pd) / maximised (k_max) over the shards -- what the caller's warnings are made from."""
         import torch
         pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
         m = pc.shape[0]
         chunk = -(-m // self.world)
         lo = min(self.rank * chunk, m)
         hi = min(lo + chunk, m)
-        pred_l, err_l, _ = self.h.predict_local(i, pc[lo:hi], max_dist, cv) if hi > lo else (np.empty(0), np.empty(0), None)
+        none = dict(n_empty=0, n_not_pd=0, k_max=0)
+        pred_l, err_l, info = self.h.predict_local(i, pc[lo:hi], max_dist, cv) if hi > lo else (np.empty(0), np.empty(0), none)
+        info = dict(none) if info is None else info
         if self.world == 1:
-            return pred_l, err_l
+            return (pred_l, err_l, info) if with_info else (pred_l, err_l)
         dev = self.device if self.device is not None else "cpu"
-        buf = torch.full((2 * chunk,), float("nan"), dtype=torch.float64, device=dev)
+        buf = torch.full((2 * chunk + 3,), float("nan"), dtype=torch.float64, device=dev)
         buf[:hi - lo] = torch.from_numpy(np.ascontiguousarray(pred_l)).to(dev)
         buf[chunk:chunk + hi - lo] = torch.from_numpy(np.ascontiguousarray(err_l)).to(dev)
+        buf[2 * chunk:] = torch.tensor([float(info["n_empty"]), float(info["n_not_pd"]), float(info["k_max"])], dtype=torch.float64).to(dev)
         allb = [torch.empty_like(buf) for _ in range(self.world)]
         self.dist.all_gather(allb, buf, group=self.group)
         allb = [b.cpu().numpy() for b in allb]
-        return (np.concatenate([b[:chunk] for b in allb])[:m], np.concatenate([b[chunk:] for b in allb])[:m])
+        pred = np.concatenate([b[:chunk] for b in allb])[:m]
+        err = np.concatenate([b[chunk:2 * chunk] for b in allb])[:m]
+        if not with_info:
+            return pred, err
+        info = dict(n_empty=int(sum(b[2 * chunk] for b in allb)), n_not_pd=int(sum(b[2 * chunk + 1] for b in allb)),
+                    k_max=int(max(b[2 * chunk + 2] for b in allb)))
+        return pred, err, info

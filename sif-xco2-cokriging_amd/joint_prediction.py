@@ -48,7 +48,13 @@ class Predictor:
     """Multivariate prediction framework (src/joint_prediction.py:13-33)."""
 
     def __init__(self, mod, mf, covariates=None, dist_units: str = "km", fast_dist: bool = True,
-                 device: int = 0) -> None:
+                 device: int = 0, devices=None) -> None:
+        """``devices=[0, 1, ...]``: the multi-GPU form (BASELINE configs[3]) -- one worker process per entry, Sigma
+        block-column-cyclic over them, panels exchanged over RCCL/xGMI at each Cholesky step, prediction points sharded
+        (workers.RankPool + distributed.DistributedJoint; the same ordinal twice rehearses it on one GPU over gloo).
+        The reference's parallel entry is likewise a keyword on the predictor (src/point_prediction.py:45-52,69-81).
+        Same results as ``device=`` to rounding; ``cross_validation`` and the exact ``_verify_model`` check are
+        single-device paths and run on ``devices[0]``."""
         if mod.n_procs != mf.n_procs:
             raise ValueError("Number of theoretical processes different from empirical processes.")
         self.n_procs = mod.n_procs
@@ -57,7 +63,10 @@ class Predictor:
         self.covariates = covariates
         self.dist_units = dist_units
         self.fast_dist = fast_dist
-        self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.device = device if self.devices is None else self.devices[0]
+        self._pool, self._pool_key = None, None
+        self.comm = {}
         self.timings = {}
         self.rhs_budget_bytes = 48 << 30   # device memory for the right-hand sides of one ck_predict call
         # _verify_model: None = exact check (Cholesky of the m x m Schur complement on the device) for up to
@@ -112,6 +121,39 @@ class Predictor:
         if self._h is not None:
             self._h.close()
         self._h, self._key = None, None
+        self._pool_key = None
+
+    def close(self):
+        """Release the device state; with ``devices=`` also end the worker processes."""
+        self.invalidate()
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _predict_on_ranks(self, i, pc):
+        """The multi-GPU form: ship model and data to the ranks when they have changed, predict on the resident factor
+        otherwise."""
+        from . import workers
+        from .model import model_arrays
+        key = self._state_key()
+        if self._pool is None:
+            self._pool = workers.RankPool(self.devices)
+        reuse = key == self._pool_key
+        if not reuse:
+            self._pool.load(model_arrays(self.mod), metric_of(self.dist_units, self.fast_dist),
+                            [np.asarray(self.mf.fields[k].coords_main, dtype=np.float64) for k in range(self.n_procs)],
+                            [np.asarray(self.mf.fields[k].values_main, dtype=np.float64) for k in range(self.n_procs)])
+            self._pool_key = None
+        pred, err = self._pool.predict_joint(i, pc, reuse_factor=reuse)
+        self._pool_key = key
+        self.timings, self.comm = self._pool.last_timings, self._pool.last_comm
+        return pred, err
 
     def _factored_handle(self):
         key = self._state_key()
@@ -127,6 +169,9 @@ class Predictor:
         """(pred, pred_err) as arrays -- the numeric body of ``__call__``
         (src/joint_prediction.py:49-78)."""
         pc = np.ascontiguousarray(np.atleast_2d(np.asarray(pcoords, dtype=np.float64)))
+        if cv_ix is None and self.devices is not None and len(self.devices) > 1:
+            self._verdict = None     # the exact _verify_model check is a single-device path: the variance test stands in
+            return self._predict_on_ranks(i, pc)
         if cv_ix is None:
             h = self._factored_handle()
             # The right-hand sides take (m + 1) x N doubles on the device: very large grids go through the

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("CK_LIB_PATH") or os.path.join(HERE, "libcokrige_hip.s
 
 METRIC_HAVERSINE = 0
 METRIC_EUCLID = 1
+PANEL_SLACK_BYTES = 64 * 512 * 8   # include/cokrige.h: CK_PANEL_SLACK_BYTES
 APPLY_SIGMA = 1
 APPLY_AUX = 2
 
@@ -54,6 +55,8 @@ _PROTOS = {
     "ck_panel_buffer": [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int64)],
     "ck_panel_apply": [c_void_p, c_int, c_int],
     "ck_panel_apply_sigma": [c_void_p, c_int, c_int, c_int],
+    "ck_panel_apply_group": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ck_panel_aux_solve": [c_void_p, c_int],
     "ck_aux_finish": [c_void_p, _dp, _dp],
     "ck_factor_info": [c_void_p, POINTER(c_int64)],
     "ck_predict_local": [c_void_p, c_int, _dp, c_int64, c_double, c_int, _dp, _dp, POINTER(c_int64), POINTER(c_int64),
@@ -323,6 +326,12 @@ class Handle:
 
     def panel_apply_sigma(self, K, J_lo, J_hi):
         _chk(lib().ck_panel_apply_sigma(self._h, int(K), int(J_lo), int(J_hi)))
+
+    def panel_apply_group(self, K0, np_, what, J_lo, J_hi, phase=0, n_phase=1):
+        _chk(lib().ck_panel_apply_group(self._h, int(K0), int(np_), int(what), int(J_lo), int(J_hi), int(phase), int(n_phase)))
+
+    def panel_aux_solve(self, K):
+        _chk(lib().ck_panel_aux_solve(self._h, int(K)))
 
     def aux_finish(self):
         pred, err = np.empty(self._m), np.empty(self._m)

@@ -30,12 +30,19 @@ from .model import configure_handle
 class Predictor:
     """Multivariate prediction framework (src/point_prediction.py:21-43)."""
 
-    def __init__(self, mod, mf, covariates=None, dist_units: str = "km", fast_dist: bool = True, device: int = 0):
+    def __init__(self, mod, mf, covariates=None, dist_units: str = "km", fast_dist: bool = True, device: int = 0,
+                 devices=None):
+        """``devices=[0, 1, ...]``: the prediction points are sharded over one worker process per GPU (observations
+        replicated, no exchange inside the computation) -- what ``partitions`` is to the reference's CPU pool
+        (src/point_prediction.py:45-52, 69-81)."""
         if mod.n_procs != mf.n_procs:
             raise ValueError("Number of theoretical processes different from empirical processes.")
         self.n_procs = mod.n_procs
         self.mod, self.mf, self.covariates = mod, mf, covariates
-        self.dist_units, self.fast_dist, self.device = dist_units, fast_dist, device
+        self.dist_units, self.fast_dist = dist_units, fast_dist
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.device = device if self.devices is None else self.devices[0]
+        self._pool, self._pool_key = None, None
         self.cv = False  # placeholder for cross-validation (src/point_prediction.py:43)
         self.info = {}
         self._h = None
@@ -56,8 +63,38 @@ class Predictor:
             self._h = h
         return self._h
 
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _predict_on_ranks(self, i, pcoords, max_dist):
+        from . import workers
+        from .model import model_arrays
+        key = _JointPredictor._state_key(self)
+        if self._pool is None:
+            self._pool = workers.RankPool(self.devices)
+        if key != self._pool_key:
+            self._pool.load(model_arrays(self.mod), metric_of(self.dist_units, self.fast_dist),
+                            [np.asarray(self.mf.fields[k].coords_main, dtype=np.float64) for k in range(self.n_procs)],
+                            [np.asarray(self.mf.fields[k].values_main, dtype=np.float64) for k in range(self.n_procs)])
+            self._pool_key = key
+        return self._pool.predict_local(i, pcoords, max_dist=max_dist, cv=self.cv)
+
     def predict_arrays(self, i: int, pcoords, max_dist: float = 1e3):
-        pred, err, info = self._handle().predict_local(i, pcoords, max_dist=max_dist, cv=self.cv)
+        if self.devices is not None and len(self.devices) > 1:
+            pred, err, info = self._predict_on_ranks(i, pcoords, max_dist)
+        else:
+            pred, err, info = self._handle().predict_local(i, pcoords, max_dist=max_dist, cv=self.cv)
         self.info = info
         if info["n_empty"]:
             warnings.warn(f"No data within maximum distance {max_dist} at {info['n_empty']} location(s).")

@@ -20,16 +20,29 @@ class FakePanelHandle:
         self.Npad = -(-self.N // NB) * NB
         self.nK = self.Npad // NB
         self.info = 0
+        self.slots = 2
 
     # -- configuration ---------------------------------------------------------------------------
     def set_partition(self, rank, world):
         self.rank, self.world = rank, world
 
+    def set_option(self, name, value):
+        if name == "recv_slots":
+            self.slots = int(value)
+        # "site_order": the stand-in always works in the caller's order
+
     def estimate_bytes(self, m):
-        return 8 * (self.Npad * self.NB * 2)
+        return 8 * (self.Npad * self.NB * self.slots)
+
+    SLACK = 64 * 512        # elements behind every panel buffer (include/cokrige.h: CK_PANEL_SLACK_BYTES)
 
     def make_arena(self, nbytes):
-        self.recv = [torch.zeros(self.Npad * self.NB, dtype=torch.float64) for _ in range(2)]
+        self.recv = [torch.zeros(self.Npad * self.NB + self.SLACK, dtype=torch.float64) for _ in range(self.slots)]
+        self.store, self.sig = {}, {}
+        for K in range(self.rank, self.nK, self.world):   # owned panels: storage now (like the library's layout), content later
+            n = (self.Npad - K * self.NB) * self.NB
+            self.store[K] = torch.zeros(n + self.SLACK, dtype=torch.float64)
+            self.sig[K] = self.store[K][:n]
         return torch.zeros(8, dtype=torch.uint8)
 
     def num_panels(self):
@@ -40,9 +53,8 @@ class FakePanelHandle:
         S = np.eye(self.Npad)
         S[:self.N, :self.N] = orc.joint_cov(self.p, self.coords, self.metric)
         NB = self.NB
-        self.sig = {}
         for K in range(self.rank, self.nK, self.world):
-            self.sig[K] = torch.from_numpy(np.ascontiguousarray(S[K * NB:, K * NB:(K + 1) * NB]).ravel().copy())
+            self.sig[K].copy_(torch.from_numpy(np.ascontiguousarray(S[K * NB:, K * NB:(K + 1) * NB]).ravel()))
         self.info = 0
 
     def aux_begin(self, i, pcoords):
@@ -53,11 +65,15 @@ class FakePanelHandle:
         X[self.m, :self.N] = np.hstack(self.values)
         self.X = X
 
-    def panel_tensor(self, K):
-        if K in self.sig:
-            return self.sig[K]
+    def panel_tensor(self, K, pad_to=0):
         rows = self.Npad - K * self.NB
-        return self.recv[K & 1][:rows * self.NB]
+        n = rows * self.NB
+        if pad_to:
+            assert 0 <= pad_to - n <= self.SLACK
+            n = pad_to
+        if K in self.sig:
+            return self.store[K][:n]
+        return self.recv[K % self.slots][:n]
 
     def panel_factor(self, K):
         NB = self.NB
@@ -84,6 +100,39 @@ class FakePanelHandle:
             C = self.sig[J].numpy().reshape(-1, NB)
             A = P[(J - K) * NB:]
             C -= A @ A[:NB].T
+
+    def panel_apply_group(self, K0, np_, what, J_lo, J_hi, phase=0, n_phase=1):
+        """include/cokrige.h: ck_panel_apply_group -- same column / piece selection as the library"""
+        NB = self.NB
+        J_lo, J_hi = max(J_lo, K0 + np_), min(J_hi, self.nK - 1)
+        if J_lo > J_hi:
+            return
+        Ps = [self.panel_tensor(K0 + p).numpy().reshape(-1, NB) for p in range(np_)]
+        if what & 1:
+            J0 = J_lo
+            while J0 <= J_hi and J0 % self.world != self.rank:
+                J0 += 1
+            J0 += phase * self.world
+            for J in range(J0, J_hi + 1, self.world * n_phase):
+                C = self.sig[J].numpy().reshape(-1, NB)
+                for p, P in enumerate(Ps):
+                    A = P[(J - K0 - p) * NB:]
+                    C -= A @ A[:NB].T
+        if what & 2:
+            tot = J_hi - J_lo + 1
+            per = -(-tot // n_phase)
+            a = J_lo + phase * per
+            b = min(J_hi, a + per - 1)
+            for J in range(a, b + 1):
+                for p, P in enumerate(Ps):
+                    K = K0 + p
+                    self.X[:, J * NB:(J + 1) * NB] -= self.X[:, K * NB:(K + 1) * NB] @ P[(J - K) * NB:(J - K + 1) * NB].T
+
+    def panel_aux_solve(self, K):
+        NB = self.NB
+        P = self.panel_tensor(K).numpy().reshape(-1, NB)
+        L = np.tril(P[:NB])
+        self.X[:, K * NB:(K + 1) * NB] = np.linalg.solve(L, self.X[:, K * NB:(K + 1) * NB].T).T
 
     def panel_apply(self, K, what):
         NB = self.NB

@@ -31,13 +31,27 @@ def _worker(rank, world, port, case, q):
     try:
         from sif_xco2_cokriging_amd.distributed import DistributedJoint
         from tests.fake_panel_handle import FakePanelHandle
-        if case in ("solve", "solve_sequential", "solve_p2p", "solve_p2p_sequential"):
+        if case.startswith("solve"):
             g = load_golden("joint_solve")
             h = FakePanelHandle(g["params_A"], [g["coords0_A"], g["coords1_A"]], [g["values0_A"], g["values1_A"]], 0)
-            r = DistributedJoint(h, rank, world, dist_module=dist, lookahead=case in ("solve", "solve_p2p"),
-                                 exchange="p2p" if "p2p" in case else "broadcast").prepare(len(g["pcoords_A"]))
+            tok = case.split("_")
+            exchange = "p2p" if "p2p" in tok else "sag" if "sag" in tok else "auto" if "auto" in tok else "broadcast"
+            group = 3 if "g3" in tok else 2 if "g2" in tok else "auto" if "gauto" in tok else 1
+            r = DistributedJoint(h, rank, world, dist_module=dist, lookahead="sequential" not in tok,
+                                 exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
+            if exchange == "auto":
+                info = r.calibrate(reps=1)
+                assert info["exchange"] in ("broadcast", "sag", "p2p") and r.exchange == info["exchange"]
+                assert all(info["calibration_ms"][k] is not None for k in ("broadcast", "sag", "p2p")), info   # all ran
+            if group == "auto":
+                pred, err = r.autotune(1, g["pcoords_A"])
+                assert r.G in (1, 3) and r.tune_info["pass_ms"] is not None
             pred, err = r.predict(1, g["pcoords_A"])
-            q.put((rank, "ok", pred, err))
+            if "again" in tok:     # the factor is resident: a second set of sites costs one solve-only sweep
+                p2, e2 = r.predict(0, g["pcoords_A"][::-1], reuse_factor=True)
+                q.put((rank, "ok", pred, err, p2[::-1], e2[::-1]))
+            else:
+                q.put((rank, "ok", pred, err))
         elif case == "vario":
             from sif_xco2_cokriging_amd.distributed import DistributedVariogram
             from tests.fake_panel_handle import FakeVarioHandle
@@ -85,17 +99,26 @@ def _run(world, case):
 
 @pytest.mark.parametrize("world,case", [(2, "solve"), (3, "solve"), (2, "solve_sequential"), (3, "solve_p2p"),
                                         (4, "solve_p2p"), (3, "solve_p2p_sequential"),
-                                        (8, "solve"), (8, "solve_p2p")])   # the node's size: more ranks than panels, empty pieces
+                                        (8, "solve"), (8, "solve_p2p"),   # the node's size: more ranks than panels, empty pieces
+                                        (2, "solve_sag"), (3, "solve_sag_g3"), (8, "solve_sag"), (3, "solve_auto"),
+                                        (2, "solve_g3"), (3, "solve_g2"), (4, "solve_p2p_g3"), (8, "solve_g3"),
+                                        (2, "solve_gauto"), (3, "solve_g3_again"), (2, "solve_again")])
 def test_joint_predict_two_ranks(world, case):
     """look-ahead schedule (asynchronous broadcast of panel K + 1 under the update by panel K) and the
-    plain factor -> broadcast -> apply sequence; the panel exchange as one broadcast or as scatter + point-to-point
-    all-gather (exchange="p2p": every rank forwards its piece to all the others)"""
+    plain factor -> broadcast -> apply sequence; the panel exchange as one broadcast, as scatter + in-place all-gather
+    ("sag") or as scatter + point-to-point all-gather ("p2p": every rank forwards its piece to all the others), chosen
+    by calibration ("auto"); the grouped schedule (g2 / g3: trailing updates for 2 / 3 panels at once with the next
+    group's panel steps and exchanges in between; gauto: timed against the per-panel one); a second prediction on the
+    resident factor (again)"""
     g = load_golden("joint_solve")
     out = _run(world, case)
-    for rank, status, pred, err in out:
+    for rank, status, pred, err, *more in out:
         assert status == "ok"
         assert np.max(np.abs(pred - g["pred_A_1"])) / np.max(np.abs(g["pred_A_1"])) < 1e-9
         assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-10
+        if more:
+            assert np.max(np.abs(more[0] - g["pred_A_0"])) / np.max(np.abs(g["pred_A_0"])) < 1e-9
+            assert np.max(np.abs(more[1] ** 2 - g["pred_err_A_0"] ** 2)) < 1e-10
     # every rank returns the same full-length vectors
     assert np.array_equal(out[0][2], out[1][2])
 
@@ -103,7 +126,7 @@ def test_joint_predict_two_ranks(world, case):
 def test_not_positive_definite_all_ranks_raise():
     g = load_golden("joint_not_pd")
     out = _run(2, "npd")
-    for rank, status, _, _ in out:
+    for rank, status, *_ in out:
         assert status == str(g["message"]), status
 
 

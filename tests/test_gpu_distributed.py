@@ -74,7 +74,7 @@ class _HostWork:
         return True
 
 
-def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast"):
+def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast", group=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -102,18 +102,26 @@ def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast"):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
-        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange).prepare(len(g["pcoords_A"]))
-        pred, err = r.predict(0, g["pcoords_A"])
+        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
+        if exchange == "auto":
+            info = r.calibrate(reps=1)
+            assert r.exchange in ("broadcast", "sag", "p2p") and info["calibration_ms"]["broadcast"] is not None, info
+        pred, err = r.autotune(0, g["pcoords_A"]) if group == "auto" else r.predict(0, g["pcoords_A"])
         assert r.timings["update_ms"] > 0 and r.timings["bcast_wait_ms"] >= 0
-        q.put((rank, pred, err, coords, values))
+        # the factor is resident: the other process at the same sites costs one exchange-and-substitute sweep
+        p1, e1 = r.predict(1, g["pcoords_A"], reuse_factor=True)
+        q.put((rank, pred, err, coords, values, p1, e1))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("via_host,big,world,exchange", [(True, False, 2, "broadcast"), (False, False, 2, "broadcast"),
-                                                         (False, True, 2, "broadcast"), (True, True, 3, "p2p")])
-def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange):
-    """(the last case: three ranks, every panel scattered by its owner and passed on point to point)"""
+@pytest.mark.parametrize("via_host,big,world,exchange,group", [
+    (True, False, 2, "broadcast", 1), (False, False, 2, "broadcast", 1), (False, True, 2, "broadcast", 1),
+    (True, True, 3, "p2p", 1), (False, True, 2, "broadcast", 3), (True, True, 3, "p2p", 2), (False, True, 3, "auto", "auto")])
+def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange, group):
+    """(p2p: three ranks, every panel scattered by its owner and passed on point to point; group 2 / 3: trailing updates
+    for that many panels at once with the next group's panel steps in between; auto: exchange and schedule chosen by
+    their own timings at warm-up)"""
     import torch.multiprocessing as mp
     from oracle import cokrige_oracle as orc
     s = socket.socket()
@@ -122,7 +130,7 @@ def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, via_host, big, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, via_host, big, exchange, group)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _queue
@@ -139,11 +147,14 @@ def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange):
         p.join(timeout=60)
         assert p.exitcode == 0
     g = load_golden("joint_solve")
-    _, pred0, err0, coords, values = out[0]
+    _, pred0, err0, coords, values, pred1, err1 = out[0]
     p = orc.Params.from_flat(g["params_A"])
     rp, re = orc.joint_predict(p, coords, values, g["pcoords_A"], 0, 0)
     assert np.max(np.abs(pred0 - rp)) / np.max(np.abs(rp)) < 1e-9
     assert np.max(np.abs(err0 ** 2 - re ** 2)) < 1e-10
+    rp1, re1 = orc.joint_predict(p, coords, values, g["pcoords_A"], 1, 0)      # solve-only sweep on the resident factor
+    assert np.max(np.abs(pred1 - rp1)) / np.max(np.abs(rp1)) < 1e-9
+    assert np.max(np.abs(err1 ** 2 - re1 ** 2)) < 1e-10
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
@@ -268,3 +279,159 @@ def test_sharded_variogram_and_local_predictor_two_ranks_one_gpu():
         assert np.array_equal(np.isnan(pred), np.isnan(ref_pred))
         np.testing.assert_allclose(pred, ref_pred, rtol=1e-12, equal_nan=True)
         np.testing.assert_allclose(err, ref_err, rtol=1e-12, equal_nan=True)
+
+
+def test_world1_grouped_step_wise_driver_matches_direct():
+    """The grouped schedule of the multi-rank driver (ck_panel_apply_group, ck_panel_aux_solve) at world = 1 against
+    ck_factor + ck_predict: same arithmetic in another grouping, equal to rounding."""
+    import torch
+    from sif_xco2_cokriging_amd import native, synth
+    from sif_xco2_cokriging_amd.distributed import DistributedJoint
+    pb = synth.conus_problem(2300, seed=5)            # N = 4 600: 9 panels, three groups of three
+    pv = pb["params"]
+
+    def mk():
+        h = native.Handle(0)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(pb["metric"])
+        for k in range(2):
+            h.set_data(k, pb["coords"][k], pb["values"][k])
+        return h
+    pc = pb["pcoords"][:900]
+    h2 = mk()
+    h2.assemble_joint()
+    assert h2.factor() == 0
+    p2, e2 = h2.predict(0, pc)
+    for G in (2, 3, 4):
+        h1 = mk()
+        r = DistributedJoint(h1, 0, 1, device=torch.device("cuda", 0), panel_group=G).prepare(len(pc))
+        p1, e1 = r.predict(0, pc)
+        assert np.max(np.abs(p1 - p2)) / np.max(np.abs(p2)) < 1e-11, G
+        assert np.max(np.abs(e1 - e2)) / np.max(np.abs(e2)) < 1e-11, G
+        h1.close()
+
+
+def _worker_fullsize(rank, world, port, q, exchange, group, n_obs):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sif_xco2_cokriging_amd import native, synth
+        from sif_xco2_cokriging_amd.distributed import DistributedJoint
+        pb = synth.conus_problem(n_obs, seed=20003)
+        pv = pb["params"]
+        h = native.Handle(0)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(pb["metric"])
+        for k in range(2):
+            h.set_data(k, pb["coords"][k], pb["values"][k])
+        torch.cuda.set_device(0)
+        r = DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", 0), exchange=exchange,
+                             panel_group=group).prepare(len(pb["pcoords"]))
+        pred, err = r.predict(0, pb["pcoords"])
+        q.put((rank, pred, err, dict(r.timings)))
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,group", [("broadcast", 1), ("sag", 3)])
+def test_full_size_two_rank_rehearsal_matches_single_process(exchange, group):
+    """The multi-rank form at the headline size -- n_obs = 20 000 per process, 79 panels, look-ahead over every owner's
+    turn, two receive slots (per-panel schedule) or six (groups of three) -- as two ranks on ONE GPU over gloo, against
+    the single-process ck_factor / ck_predict result on the same inputs: 1e-11 relative.  (RCCL refuses two ranks on
+    one device; the ranks' kernels, buffers, schedules and collective calls are the ones an 8-GPU run executes.)"""
+    import torch.multiprocessing as mp
+    from sif_xco2_cokriging_amd import native, synth
+    n_obs = 20000
+    pb = synth.conus_problem(n_obs, seed=20003)
+    pv = pb["params"]
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(pb["metric"])
+    for k in range(2):
+        h.set_data(k, pb["coords"][k], pb["values"][k])
+    h.assemble_joint()
+    assert h.factor() == 0
+    rp, re = h.predict(0, pb["pcoords"])
+    h.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker_fullsize, args=(r, world, port, q, exchange, group, n_obs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+            assert time.time() - t0 < 600, "timeout"
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, pred, err, tm in out:
+        assert np.max(np.abs(pred - rp)) / np.max(np.abs(rp)) < 1e-11
+        assert np.max(np.abs(err - re)) / np.max(np.abs(re)) < 1e-11
+        assert tm["update_ms"] > 0
+
+
+def test_predictor_devices_keyword_spawns_ranks_and_matches_single_device():
+    """joint_prediction.Predictor(..., devices=[0, 0]) / point_prediction.Predictor(..., devices=[0, 0]): fresh worker
+    processes (two ranks sharing the one GPU over gloo -- [0, 1, ...] on a node runs the same code over RCCL), same
+    Dataset as the single-device predictor; a second call reuses the ranks' resident factor; a Sigma that is not
+    positive definite raises scipy's message in the caller."""
+    from numpy.linalg import LinAlgError
+    from sif_xco2_cokriging_amd import fields, joint_prediction, model, point_prediction
+    g = load_golden("joint_solve")
+    rng = np.random.default_rng(3)
+    npts = 2600
+    pts = np.column_stack([rng.uniform(25, 50, npts), rng.uniform(-120, -70, npts)])
+    coords = [pts[:1400], pts[1200:]]
+    values = [rng.standard_normal(len(c)) for c in coords]
+    mod = model.MultivariateMatern()
+    mod.params.set_values(g["params_A"])
+    mf = fields.MultiField([fields.Field(coords[0], values[0]), fields.Field(coords[1], values[1])])
+    pc = g["pcoords_A"]
+    one = joint_prediction.Predictor(mod, mf)
+    two = joint_prediction.Predictor(mod, mf, devices=[0, 0])
+    try:
+        for i in (0, 1):                      # the second call runs on the ranks' resident factor
+            a = one(i, pc, postprocess=False)
+            b = two(i, pc, postprocess=False)
+            pa, pb_ = np.asarray(a["pred"]).ravel(), np.asarray(b["pred"]).ravel()
+            ea, eb = np.asarray(a["pred_err"]).ravel(), np.asarray(b["pred_err"]).ravel()
+            assert np.max(np.abs(pa - pb_)) / np.max(np.abs(pa)) < 1e-11
+            assert np.max(np.abs(ea - eb)) / np.max(np.abs(ea)) < 1e-11
+        assert two.timings["update_ms"] > 0
+        lp1 = point_prediction.Predictor(mod, mf)
+        lp2 = point_prediction.Predictor(mod, mf, devices=[0, 0])
+        x = lp1.predict_arrays(1, pc, max_dist=300.0)
+        y = lp2.predict_arrays(1, pc, max_dist=300.0)
+        assert lp1.info == lp2.info
+        np.testing.assert_allclose(y[0], x[0], rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(y[1], x[1], rtol=1e-12, equal_nan=True)
+        lp2.close()
+    finally:
+        two.close()
+    npd = load_golden("joint_not_pd")
+    mod2 = model.MultivariateMatern()
+    mod2.params.set_values(npd["params"])
+    mf2 = fields.MultiField([fields.Field(npd["coords0"], np.zeros(len(npd["coords0"]))),
+                             fields.Field(npd["coords1"], np.zeros(len(npd["coords1"])))])
+    bad = joint_prediction.Predictor(mod2, mf2, devices=[0, 0])
+    try:
+        with pytest.raises(LinAlgError) as e:
+            bad.predict_arrays(0, npd["coords0"][:5])
+        assert str(e.value) == str(npd["message"])
+    finally:
+        bad.close()
