@@ -227,6 +227,11 @@ int ck_hilbert_order(const double* coords_host, int64_t n, int64_t* perm_host);
  * (upper triangle zero-filled); small N only (tests).  Rows / columns are in the handle's INTERNAL
  * site order: process 0 then process 1, each in the order ck_debug_site_order reports. */
 int ck_debug_get_lower(ck_handle* h, double* out_host, int64_t n);
+/* Entries (rows[e], cols[e]) of Sigma -- after ck_assemble_joint -- or of its factor L L^T = Sigma -- after ck_factor; then
+ * the lower triangle, (r, c) and (c, r) both give L[max][min] -- with the indices in the CALLER's stacked order
+ * (process 0 sites, then process 1), whatever the internal site order; any n (parity tests at sizes where the dense
+ * matrix does not fit a host array: sampled entries of the table-path assembly, sampled rows of the factor). */
+int ck_debug_get_entries(ck_handle* h, const int64_t* rows_host, const int64_t* cols_host, int64_t n, double* out_host);
 /* perm_out[j] = caller's index (within process k) of the site at internal position j.  Identity
  * with option site_order = 0; a Hilbert-curve order with site_order = 1 (the default). */
 int ck_debug_site_order(ck_handle* h, int k, int64_t* perm_out, int64_t n_k);

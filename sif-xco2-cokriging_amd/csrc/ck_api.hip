@@ -2282,6 +2282,51 @@ extern "C" int ck_debug_get_lower(ck_handle* h, double* out, int64_t n) {
     return 0;
 }
 
+// out[e] = entry (rows[e], cols[e]) of the lower triangle held in the packed panels (internal, padded indices; r >= c)
+__global__ void k_gather_entries(double* const* __restrict__ sigptr, const long long* __restrict__ rows,
+                                 const long long* __restrict__ cols, long n, double* __restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const long r = rows[e], c = cols[e];
+    const long K = c / CK_NB;
+    out[e] = sigptr[K][(r - K * CK_NB) * CK_NB + (c - K * CK_NB)];
+}
+
+extern "C" int ck_debug_get_entries(ck_handle* h, const int64_t* rows, const int64_t* cols, int64_t n, double* out) {
+    CHKH(h);
+    if (!h->assembled) return fail("ck_assemble_joint has not been called");
+    if (h->world != 1) return fail("ck_debug_get_entries is the single-process form");
+    if (n < 0 || (n > 0 && (!rows || !cols || !out))) return fail("bad arguments");
+    if (n == 0) return 0;
+    // caller's stacked index (process 0 sites, then process 1) -> internal padded index
+    std::vector<int64_t> inv((size_t)h->N);
+    for (int k = 0; k < h->n_procs; ++k) {
+        const int64_t off_c = k == 0 ? 0 : h->n[0], off_i = k == 0 ? 0 : h->n0p;
+        for (int64_t j = 0; j < h->n[k]; ++j) inv[(size_t)(off_c + h->perm[k][(size_t)j])] = off_i + j;
+    }
+    std::vector<long long> hr((size_t)n), hc((size_t)n);
+    for (int64_t e = 0; e < n; ++e) {
+        if (rows[e] < 0 || rows[e] >= h->N || cols[e] < 0 || cols[e] >= h->N) return fail("entry index out of range");
+        long long r = inv[(size_t)rows[e]], c = inv[(size_t)cols[e]];
+        if (r < c) std::swap(r, c);   // symmetric: only the lower triangle is stored
+        hr[(size_t)e] = r;
+        hc[(size_t)e] = c;
+    }
+    DevTemps tmp;
+    long long *dr = nullptr, *dc = nullptr;
+    double* dout = nullptr;
+    HIPCHK(tmp.get(&dr, (size_t)n * 8));
+    HIPCHK(tmp.get(&dc, (size_t)n * 8));
+    HIPCHK(tmp.get(&dout, (size_t)n * 8));
+    HIPCHK(hipMemcpyAsync(dr, hr.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dc, hc.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    k_gather_entries<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_sigptr, dr, dc, (long)n, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
     CHKH(h);
     int32_t* d = nullptr;

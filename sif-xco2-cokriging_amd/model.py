@@ -227,9 +227,12 @@ class MultivariateMatern:
         nz = yfit != 0.0
         return np.sum(counts[nz] * ((ydata[nz] - yfit[nz]) / yfit[nz]) ** 2)
 
-    def fit(self, estimate, guess: MaternParams = None):
+    def fit(self, estimate, guess: MaternParams = None, polish: bool = False):
         """Fit the parameters to the empirical (cross-)semivariograms simultaneously by composite
-        weighted least squares -- same flow, optimiser and warning as src/model.py:285-317."""
+        weighted least squares -- same flow, optimiser and warning as src/model.py:285-317.
+        ``polish`` (not in the reference; off by default, so the default call is the reference's): restart the
+        optimiser once from its own answer and keep the better of the two -- L-BFGS-B on finite-difference gradients
+        stops early on this cost's flat valley floors (the reference's recorded run: 1618.19, restarted: 1608.19)."""
         if estimate.config.n_procs != self.n_procs:
             raise ValueError("Number of theoretical processes different from empirical processes.")
         if guess is None:
@@ -239,6 +242,10 @@ class MultivariateMatern:
             self.params.set_bounds(**{p.name: p.bounds for p in guess._params})
         bounds = self.params.get_bounds()
         optim_result = minimize(self._composite_wls, init_params, args=(estimate.df,), method="L-BFGS-B", bounds=bounds)
+        if polish:
+            again = minimize(self._composite_wls, optim_result.x, args=(estimate.df,), method="L-BFGS-B", bounds=bounds)
+            if again.fun <= optim_result.fun:
+                optim_result = again
         if optim_result.success == False:   # noqa: E712  (as the reference)
             warnings.warn("ERROR: optimization did not converge.")
         self.params.set_values(optim_result.x)

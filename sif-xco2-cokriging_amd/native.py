@@ -70,6 +70,7 @@ _PROTOS = {
     "ck_hilbert_order": [_dp, c_int64, POINTER(c_int64)],
     "ck_debug_get_lower": [c_void_p, _dp, c_int64],
     "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
+    "ck_debug_get_entries": [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int64, _dp],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
@@ -388,6 +389,17 @@ class Handle:
     def debug_get_lower(self, n):
         out = np.empty((n, n))
         _chk(lib().ck_debug_get_lower(self._h, _p(out), int(n)))
+        return out
+
+    def debug_get_entries(self, rows, cols):
+        """Sigma[rows[e], cols[e]] (after assemble_joint) or L[max, min] (after factor); caller's stacked site order."""
+        r = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        c = np.ascontiguousarray(cols, dtype=np.int64).ravel()
+        if r.size != c.size:
+            raise ValueError("rows and cols disagree in length")
+        out = np.empty(r.size)
+        _chk(lib().ck_debug_get_entries(self._h, r.ctypes.data_as(POINTER(c_int64)), c.ctypes.data_as(POINTER(c_int64)), r.size,
+                                        _p(out)))
         return out
 
     def debug_site_order(self, k, n_k):

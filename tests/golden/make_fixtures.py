@@ -579,6 +579,44 @@ def fixture_fit():
     out["guess_x0"] = np.array([1.0, 1.0, 1.0, 1.0, 1.0, 400.0, 400.0, 400.0, 0.01, 0.01, -0.3])
     out["guess_fit_x"] = mod2.params.get_values().astype(float)
     out["guess_fit_cost"] = np.array(mod2.fit_result.cost)
+    # Where the REFERENCE's own optimiser stops when its inputs -- the bin means -- change in the last digits (1e-14
+    # relative; another summation order does as much): its L-BFGS-B runs on finite-difference gradients of a cost whose
+    # K_nu differences reach the gradient at 1e-3, so the run is chaotic at that level and ends in one of two valleys.
+    # Row 0 is the unperturbed run (= fit_x / guess_fit_x).  The tests bound our optimum by THESE, not by anything
+    # computed at test time.
+    import copy
+
+    def spread(start_guess):
+        costs, xs = [], []
+        for seed in (None, 0, 1, 2, 3, 4):
+            est_p = copy.copy(est)
+            est_p.df = est.df.copy()
+            if seed is not None:
+                prng2 = np.random.default_rng(seed)
+                for (i, j) in ((0, 0), (0, 1), (1, 1)):
+                    sel = (est_p.df.index.get_level_values("i") == i) & (est_p.df.index.get_level_values("j") == j)
+                    m = est_p.df.loc[sel, "bin_mean"].values.astype(float)
+                    est_p.df.loc[sel, "bin_mean"] = m * (1.0 + 1e-14 * prng2.standard_normal(len(m)))
+            if start_guess:
+                gs = model.MaternParams(n_procs=2)
+                gs.set_values(np.array([1.0, 1.0, 1.0, 1.0, 1.0, 400.0, 400.0, 400.0, 0.01, 0.01, -0.3]))
+                gs.set_bounds(nu=(0.3, 2.5), len_scale=(2e2, 1e3))
+                m3 = model.MultivariateMatern(n_procs=2, params=gs)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    m3.fit(est_p, guess=gs)
+            else:
+                m3 = model.MultivariateMatern(n_procs=2)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    m3.fit(est_p)
+            costs.append(float(m3.fit_result.cost))
+            xs.append(m3.params.get_values().astype(float))
+        return np.array(costs), np.array(xs)
+    out["spread_costs"], out["spread_x"] = spread(False)
+    out["guess_spread_costs"], out["guess_spread_x"] = spread(True)
+    print("reference fit spread (default start):", out["spread_costs"], out["spread_x"][:, [6, 10]].T)
+    print("reference fit spread (guess start):  ", out["guess_spread_costs"], out["guess_spread_x"][:, [6, 10]].T)
     print("fit:", out["fit_x"], out["fit_cost"], "warned", out["fit_warned"])
     print("guess fit:", out["guess_fit_x"], out["guess_fit_cost"])
     save("model_fit", **out)

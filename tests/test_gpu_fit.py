@@ -60,34 +60,54 @@ def test_composite_wls_vs_reference():
     assert mod._weighted_least_squares(y, f, c) == pytest.approx(5.0 + 6.0 + 7.0 / 16.0)
 
 
-def _reference_spread(groups, x0=None, bounds=None, seeds=5):
-    """The largest cost at which the reference's own optimiser (oracle restatement: the same scipy call) stops when its
-    inputs -- the bin means -- are perturbed in the last digits (1e-14 relative): from the default start it ends at
-    1618.19, 1605.9 ... 1609.4 or 1781.30 (a second valley, len_12 = 500, rho_12 = -0.06), two seeds in six there."""
-    costs = [float(orc.fit(groups, x0=x0, bounds=bounds)[1])]
-    for s in range(seeds):
-        rng = np.random.default_rng(s)
-        pg = {k: (h, m * (1.0 + 1e-14 * rng.standard_normal(len(m))), c) for k, (h, m, c) in groups.items()}
-        costs.append(float(orc.fit(pg, x0=x0, bounds=bounds)[1]))
-    return max(costs)
+def _valleys(costs, xs):
+    """The reference's runs (tests/golden/model_fit.npz: spread_costs / spread_x -- the REFERENCE's own fit on bin means
+    perturbed by 1e-14, row 0 the unperturbed run) grouped into valleys: runs whose cost agrees within 2 % and whose cross
+    parameters (len_12, rho_12) are neighbours.  -> list of (max cost, mean len_12, mean rho_12, rows)."""
+    costs, xs = np.asarray(costs, float), np.asarray(xs, float)
+    left, out = list(range(len(costs))), []
+    while left:
+        k = left[0]
+        grp = [r for r in left if abs(costs[r] - costs[k]) <= 0.02 * costs[k] and abs(xs[r, 6] - xs[k, 6]) <= 0.25 * xs[k, 6]
+               and abs(xs[r, 10] - xs[k, 10]) <= 0.08]
+        out.append((float(costs[grp].max()), float(xs[grp, 6].mean()), float(xs[grp, 10].mean()), grp))
+        left = [r for r in left if r not in grp]
+    return out
 
 
-def _check_fit(mod, groups, ref_x, ref_cost, bounds=None, x0=None):
+def _check_fit(mod, groups, ref_x, ref_cost, spread_costs, spread_x, bounds=None, label=""):
     """What "the same fit" can mean for L-BFGS-B on finite-difference gradients: the reference's run
     stops on a flat valley floor and is not reproducible beyond a few percent in the parameters
     (restarting the reference's own optimiser from its recorded answer moves on: 1618.19 -> 1608.19,
     scripts/diag_fit.py), because 1e-15 differences in K_nu reach the gradient as 1e-3 -- and a change in the
-    last digits of the bin means (another summation order in the variogram kernel) can send it into another valley.  So:
-    (1) our cost function IS the reference's at our optimum; (2) our optimum is at least as good as
-    what the reference's optimiser reaches on inputs perturbed in the last digits (_reference_spread; the recorded
-    optimum is one of those); (3) the reference's optimiser (oracle), restarted at our optimum, has nowhere
-    to go; (4) the marginal parameters agree to the valley's width (the cross parameters nu_12,
-    len_12, rho_12 are weakly identified by one cross-variogram: the reference's guess run stops at
-    len_12 = 424, rho_12 = -0.10 with cost 1795.8, the converged point is len_12 = 200, rho_12 = -0.29)."""
+    last digits of the bin means (another summation order in the variogram kernel) can send it into another valley:
+    the fixture holds where the REFERENCE's fit ends on inputs perturbed by 1e-14 (from the default start: 1605.9 ...
+    1618.2 with len_12 = 201 ... 216, rho_12 = -0.27 ... -0.29 in five runs of six, 1781.30 with len_12 = 500,
+    rho_12 = -0.06 in one).  So:
+    (1) our cost function IS the reference's at our optimum;
+    (2) our optimum is at least as good as the BEST run of the reference, or it lies in one of the reference's valleys --
+        its cross parameters are that valley's -- and is at least as good as the worst run the reference itself ends
+        with in THAT valley (nothing here is computed at test time);
+    (3) the reference's optimiser (oracle), restarted at our optimum, has nowhere to go;
+    (4) the marginal parameters agree with the recorded run to the valley's width (the cross parameters nu_12,
+        len_12, rho_12 are weakly identified by one cross-variogram)."""
     x = mod.params.get_values().astype(float)
     cost = float(mod.fit_result.cost)
     np.testing.assert_allclose(cost, orc.composite_wls(x, groups), rtol=1e-9)
-    assert cost <= max(ref_cost, _reference_spread(groups, x0=x0, bounds=bounds)) * (1.0 + 1e-3)
+    assert spread_costs[0] == pytest.approx(ref_cost, rel=1e-12)      # row 0 is the recorded run
+    valleys = _valleys(spread_costs, spread_x)
+    near = min(valleys, key=lambda v: abs(x[6] - v[1]) / v[1] + abs(x[10] - v[2]))
+    print(f"fit{label}: cost {cost:.2f}, len_12 {x[6]:.1f}, rho_12 {x[10]:.3f} -> the reference's valley with cost <= {near[0]:.2f} "
+          f"(len_12 {near[1]:.1f}, rho_12 {near[2]:.3f}; {len(near[3])} of its {len(spread_costs)} runs end there); "
+          f"all valleys: {[(round(v[0], 2), len(v[3])) for v in valleys]}")
+    in_valley = abs(x[6] - near[1]) <= 0.25 * near[1] and abs(x[10] - near[2]) <= 0.08
+    if cost <= float(np.min(spread_costs)) * (1.0 + 1e-3):
+        # at least as good as the BEST run of the reference: nothing more to ask, wherever it lies (from the guess start the
+        # device's K_nu sends L-BFGS-B down to 1665.1 at the len_12 bound, every run of the reference stops at 1795.6 ... 1796.1)
+        print(f"fit{label}: at or below the best of the reference's runs ({float(np.min(spread_costs)):.2f})")
+    else:
+        assert in_valley, "cross parameters in none of the reference's valleys"
+        assert cost <= near[0] * (1.0 + 1e-3)
     xo, co, _ = orc.fit(groups, x0=x, bounds=bounds)
     assert co <= cost * (1.0 + 1e-12) and co >= cost * (1.0 - 1e-4)
     np.testing.assert_allclose(xo, x, rtol=1e-3, atol=1e-4)
@@ -105,7 +125,7 @@ def test_fit_vs_reference():
         warnings.simplefilter("always")
         assert mod.fit(est) is mod
     assert int(any("did not converge" in str(x.message) for x in w)) == int(g["fit_warned"])
-    _check_fit(mod, groups, g["fit_x"], float(g["fit_cost"]))
+    _check_fit(mod, groups, g["fit_x"], float(g["fit_cost"]), g["spread_costs"], g["spread_x"], label=" (fixture's bin means)")
     fr = mod.fit_result
     assert fr.cs_valid is None and fr.config is est.config and fr.df_empirical is est.df
     th = fr.df_theoretical
@@ -127,7 +147,16 @@ def test_fit_vs_reference():
     b[2:5] = [(0.3, 2.5)] * 3
     b[5:8] = [(2e2, 1e3)] * 3
     assert [tuple(t) for t in mod2.params.get_bounds()] == b
-    _check_fit(mod2, groups, g["guess_fit_x"], float(g["guess_fit_cost"]), bounds=b, x0=np.asarray(g["guess_x0"], dtype=float))
+    _check_fit(mod2, groups, g["guess_fit_x"], float(g["guess_fit_cost"]), g["guess_spread_costs"], g["guess_spread_x"], bounds=b,
+               label=" (guess start)")
+    # optional product knob (off by default: the reference's call stays the default): one restart of the optimiser from its
+    # own answer -- which the reference's recorded run shows would help it too (1618.19 -> 1608.19)
+    mod3 = model.MultivariateMatern(n_procs=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod3.fit(est, polish=True)
+    assert float(mod3.fit_result.cost) <= float(mod.fit_result.cost) * (1.0 + 1e-12)
+    print(f"fit(polish=True): cost {float(mod.fit_result.cost):.2f} -> {float(mod3.fit_result.cost):.2f}")
     # process-count mismatch (src/model.py:293-296)
     with pytest.raises(ValueError, match="Number of theoretical processes"):
         model.MultivariateMatern(n_procs=1).fit(est)
@@ -154,7 +183,7 @@ def test_variogram_to_fit_to_prediction_flow():
     # on the groups the fit actually saw
     groups = {(i, j): (est.df.loc[(i, j)]["bin_center"].values, est.df.loc[(i, j)]["bin_mean"].values,
                        est.df.loc[(i, j)]["bin_count"].values) for (i, j) in PAIRS}
-    _check_fit(mod, groups, g["fit_x"], float(g["fit_cost"]))
+    _check_fit(mod, groups, g["fit_x"], float(g["fit_cost"]), g["spread_costs"], g["spread_x"], label=" (device's bin means)")
     x = mod.params.get_values()
     pc = pd.DataFrame({"lat": np.linspace(30, 45, 12), "lon": np.linspace(-110, -80, 12)})
     P = joint_prediction.Predictor(mod, mf)
