@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 # CK_BUILD_OUT: build an EXPERIMENTAL library next to the product one (own object directory), to be loaded with
 # CK_LIB_PATH=<that file> (native.py) -- the product library is never overwritten by an experiment
 OUT = os.environ.get("CK_BUILD_OUT") or os.path.join(HERE, "libcokrige_hip.so")
-SOURCES = ["ck_api.hip", "ck_cov.hip", "ck_la.hip", "ck_vario.hip", "ck_local.hip", "ck_model.cpp"]
+SOURCES = ["ck_api.hip", "ck_cov.hip", "ck_la.hip", "ck_vario.hip", "ck_local.hip", "ck_model.cpp", "ck_host.cpp"]
 ARCH = "gfx950"
 # ck_vario.hip: the SLP vectoriser packs the binning kernel's per-pair slot counters into 16-bit lanes (v_perm /
 # v_pk_add_u16) -- more instructions than the v_addc chain it replaces

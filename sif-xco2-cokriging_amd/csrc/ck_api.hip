@@ -25,16 +25,13 @@
 #include <vector>
 
 #include "../../include/cokrige.h"
+#include "ck_host.h"
 #include "ck_internal.h"
 #include "ck_model.h"
 
 static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-static thread_local std::string g_err;
-static int fail(const std::string& msg) {
-    g_err = msg;
-    return -1;
-}
+static int fail(const std::string& msg) { return ck_fail(msg); }   // thread-local text: ck_host.cpp (ck_last_error)
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -187,7 +184,6 @@ struct ck_handle {
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
 };
 
-extern "C" const char* ck_last_error(void) { return g_err.c_str(); }
 extern "C" int ck_version(void) { return 100; }
 extern "C" int ck_device_count(int* n) {
     HIPCHK(hipGetDeviceCount(n));
@@ -433,153 +429,8 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     return 0;
 }
 
-// fn(thread, begin, end) over [0, n) on a few host threads when n is large
-template <class F>
-static void host_parallel(int64_t n, F fn) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = n < 100000 ? 1 : (int)std::max(1u, std::min(8u, hw ? hw : 1u));
-    if (nt == 1) {
-        fn(0, 0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
-    for (auto& x : th) x.join();
-}
-static int host_parallel_threads(int64_t n) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    return n < 100000 ? 1 : (int)std::max(1u, std::min(8u, hw ? hw : 1u));
-}
-
-// Position along the Hilbert curve of order 16 through the unit square (x, y in [0, 65536)).
-static uint64_t hilbert_key(uint32_t x, uint32_t y) {
-    uint64_t d = 0;
-    for (uint32_t s = 32768; s > 0; s >>= 1) {
-        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
-        d += (uint64_t)s * s * ((3u * rx) ^ ry);
-        if (ry == 0) {   // rotate the quadrant (only the bits below s matter from here on)
-            if (rx == 1) {
-                x = s - 1 - x;
-                y = s - 1 - y;
-            }
-            const uint32_t t = x;
-            x = y;
-            y = t;
-        }
-    }
-    return d;
-}
-
-// perm <- the indices 0..n-1 ordered along the Hilbert curve through the box [lo, hi]^2 of the
-// 2-column coordinates (stable: coincident sites keep the caller's order)
-static void hilbert_order(const double* xy, int64_t n, const double lo[2], const double hi[2],
-                          std::vector<int64_t>& perm) {
-    const double sx = hi[0] > lo[0] ? 65536.0 / (hi[0] - lo[0]) : 0.0, sy = hi[1] > lo[1] ? 65536.0 / (hi[1] - lo[1]) : 0.0;
-    auto key_of = [&](int64_t k) -> uint32_t {   // order-16 curve: the key fits 32 bits
-        double fx = (xy[2 * k] - lo[0]) * sx, fy = (xy[2 * k + 1] - lo[1]) * sy;
-        fx = fx >= 0.0 ? (fx < 65535.0 ? fx : 65535.0) : 0.0;   // also catches NaN
-        fy = fy >= 0.0 ? (fy < 65535.0 ? fy : 65535.0) : 0.0;
-        return (uint32_t)hilbert_key((uint32_t)fx, (uint32_t)fy);
-    };
-    perm.resize((size_t)n);
-    if (n < 4096) {
-        std::vector<std::pair<uint32_t, int64_t>> key((size_t)n);
-        for (int64_t k = 0; k < n; ++k) key[(size_t)k] = {key_of(k), k};
-        std::stable_sort(key.begin(), key.end(),
-                         [](const std::pair<uint32_t, int64_t>& a, const std::pair<uint32_t, int64_t>& b) { return a.first < b.first; });
-        for (int64_t k = 0; k < n; ++k) perm[(size_t)k] = key[(size_t)k].second;
-        return;
-    }
-    // large sets (a million soundings of a variogram): a stable LSD radix sort of (key, index) in three 11-bit passes
-    // on a few threads -- every thread counts and scatters its own contiguous piece, the pieces' bucket offsets are laid
-    // out thread after thread, so equal keys keep the caller's order.  One team of threads runs all the phases (a
-    // spinning barrier in between; spawning a team per phase cost more than the phases), on uninitialised buffers
-    // first touched by the threads that use them.  Per million points: comparison sort 270 ms, two 16-bit passes on one
-    // thread 13 ms; with this sort, the bounding box and the gather on the same threads ck_vario_begin as a whole went
-    // from 23 to 10.5 ms.
-    const int nt = host_parallel_threads(n);
-    const int NBK = 2048;
-    std::unique_ptr<uint32_t[]> buf(new uint32_t[(size_t)4 * (size_t)n]);
-    uint32_t *ka = buf.get(), *kb = ka + n, *ia = kb + n, *ib = ia + n;
-    std::vector<int64_t> hist((size_t)nt * NBK);
-    std::atomic<int> arrived{0}, generation{0};
-    auto barrier = [&]() {
-        const int g = generation.load(std::memory_order_acquire);
-        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {
-            arrived.store(0, std::memory_order_relaxed);
-            generation.fetch_add(1, std::memory_order_acq_rel);
-        } else {
-            while (generation.load(std::memory_order_acquire) == g) std::this_thread::yield();
-        }
-    };
-    auto work = [&](int t) {
-        const int64_t b = n * t / nt, e = n * (t + 1) / nt;
-        int64_t* hh = &hist[(size_t)t * NBK];
-        uint32_t *sk = ka, *si = ia, *dk = kb, *di = ib;
-        for (int64_t k = b; k < e; ++k) {
-            sk[k] = key_of(k);
-            si[k] = (uint32_t)k;
-        }
-        for (int pass = 0; pass < 3; ++pass) {
-            const int sh = 11 * pass;
-            for (int bk = 0; bk < NBK; ++bk) hh[bk] = 0;
-            for (int64_t k = b; k < e; ++k) ++hh[(sk[k] >> sh) & (NBK - 1)];
-            barrier();
-            if (t == 0) {
-                int64_t run = 0;
-                for (int bk = 0; bk < NBK; ++bk)
-                    for (int q = 0; q < nt; ++q) {
-                        const int64_t c = hist[(size_t)q * NBK + bk];
-                        hist[(size_t)q * NBK + bk] = run;
-                        run += c;
-                    }
-            }
-            barrier();
-            for (int64_t k = b; k < e; ++k) {
-                const int64_t p = hh[(sk[k] >> sh) & (NBK - 1)]++;
-                dk[p] = sk[k];
-                di[p] = si[k];
-            }
-            barrier();
-            std::swap(sk, dk);
-            std::swap(si, di);
-        }
-        for (int64_t k = b; k < e; ++k) perm[(size_t)k] = (int64_t)si[k];
-    };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
-}
-
-static void bounding_box(const double* xy, int64_t n, double lo[2], double hi[2]) {
-    const int nt = host_parallel_threads(n);
-    std::vector<double> part((size_t)nt * 4);
-    host_parallel(n, [&](int t, int64_t b, int64_t e) {
-        double l0 = 1e300, l1 = 1e300, h0 = -1e300, h1 = -1e300;
-        for (int64_t k = b; k < e; ++k) {
-            l0 = fmin(l0, xy[2 * k]);
-            h0 = fmax(h0, xy[2 * k]);
-            l1 = fmin(l1, xy[2 * k + 1]);
-            h1 = fmax(h1, xy[2 * k + 1]);
-        }
-        part[(size_t)t * 4] = l0;
-        part[(size_t)t * 4 + 1] = l1;
-        part[(size_t)t * 4 + 2] = h0;
-        part[(size_t)t * 4 + 3] = h1;
-    });
-    for (int t = 0; t < nt; ++t) {
-        lo[0] = fmin(lo[0], part[(size_t)t * 4]);
-        lo[1] = fmin(lo[1], part[(size_t)t * 4 + 1]);
-        hi[0] = fmax(hi[0], part[(size_t)t * 4 + 2]);
-        hi[1] = fmax(hi[1], part[(size_t)t * 4 + 3]);
-    }
-}
-
+// (thread team, Hilbert order, bounding box, the reference's distance arithmetic, the variogram's level planning and tie
+// decisions: ck_host.cpp -- host-only code, also built with the CPU sanitizers by tests/test_host_sanitize.py)
 // Decide the padded layout, upload sites / values, allocate the owned panels.
 static int ensure_layout(ck_handle* h) {
     if (h->layout_ready) return 0;
@@ -604,12 +455,12 @@ static int ensure_layout(ck_handle* h) {
     }
     // stage coords -> device, transform
     double blo[2] = {1e300, 1e300}, bhi[2] = {-1e300, -1e300};
-    for (int k = 0; k < h->n_procs; ++k) bounding_box(h->h_coords[k].data(), h->n[k], blo, bhi);
+    for (int k = 0; k < h->n_procs; ++k) ck_host_bounding_box(h->h_coords[k].data(), h->n[k], blo, bhi);
     std::vector<double> hc(2 * Np, 0.0), hz(Np, 0.0);
     for (int k = 0; k < h->n_procs; ++k) {
         const int64_t nk = h->n[k], off = k == 0 ? 0 : h->n0p;
         if (h->site_order) {
-            hilbert_order(h->h_coords[k].data(), nk, blo, bhi, h->perm[k]);
+            ck_host_hilbert_order(h->h_coords[k].data(), nk, blo, bhi, h->perm[k]);
         } else {
             h->perm[k].resize((size_t)nk);
             for (int64_t j = 0; j < nk; ++j) h->perm[k][(size_t)j] = j;
@@ -1263,8 +1114,8 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
     h->p_sorted = may_sort && h->site_order && m >= 256;
     if (h->p_sorted) {
         double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
-        bounding_box(pcoords, m, lo, hi);
-        hilbert_order(pcoords, m, lo, hi, h->pperm);
+        ck_host_bounding_box(pcoords, m, lo, hi);
+        ck_host_hilbert_order(pcoords, m, lo, hi, h->pperm);
         sorted.resize((size_t)(2 * m));
         for (int64_t j = 0; j < m; ++j) {
             sorted[2 * j] = pcoords[2 * h->pperm[(size_t)j]];
@@ -1827,10 +1678,10 @@ static int vario_upload(ck_handle* h, const double* coords, const double* vals, 
     host_vals.assign(vals, vals + n);
     if (h->site_order && n >= 2048) {
         double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
-        bounding_box(coords, n, lo, hi);
+        ck_host_bounding_box(coords, n, lo, hi);
         std::vector<int64_t> perm;
-        hilbert_order(coords, n, lo, hi, perm);
-        host_parallel(n, [&](int, int64_t b, int64_t e2) {
+        ck_host_hilbert_order(coords, n, lo, hi, perm);
+        ck_host_parallel(n, [&](int, int64_t b, int64_t e2) {
             for (int64_t k = b; k < e2; ++k) {
                 const int64_t e = perm[(size_t)k];
                 host_coords[2 * k] = coords[2 * e];
@@ -1849,69 +1700,6 @@ static int vario_upload(ck_handle* h, const double* coords, const double* vals, 
     ck_launch_vario_prep(h->stream, stage, n, h->metric, *u, *u + n, *u + 2 * n);
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
-}
-
-// The reference's own distance arithmetic, on the host with libm -- bit for bit what src/fields.py:332-342
-// returns: sklearn's haversine_distances (Cython on libm's sin / cos / asin / sqrt) of np.radians(X) times 6371,
-// or scipy's cdist.  The variogram kernels leave every pair whose bin or retention they cannot decide beyond
-// rounding to this function (and the test suite checks it against sklearn / scipy bit by bit on the CPU).
-static double ref_distance(int metric, const double* a, const double* b) {
-#pragma clang fp contract(off)
-    if (metric == CK_METRIC_EUCLID) {
-        const double d0 = a[0] - b[0], d1 = a[1] - b[1];
-        const double s0 = d0 * d0;
-        const double s1 = d1 * d1;
-        return sqrt(s0 + s1);
-    }
-    const double lat1 = a[0] * CK_DEG2RAD, lon1 = a[1] * CK_DEG2RAD, lat2 = b[0] * CK_DEG2RAD, lon2 = b[1] * CK_DEG2RAD;
-    const double sin_0 = sin(0.5 * (lat1 - lat2));
-    const double sin_1 = sin(0.5 * (lon1 - lon2));
-    const double c = cos(lat1) * cos(lat2) * sin_1 * sin_1;
-    const double r = sin_0 * sin_0 + c;
-    const double d = 2 * asin(sqrt(r));
-    return d * CK_EARTH_RADIUS_KM;
-}
-
-extern "C" int ck_hilbert_order(const double* coords, int64_t n, int64_t* perm_out) {
-    if (n < 0 || (n > 0 && (!coords || !perm_out))) return fail("bad arguments");
-    if (n >= (1LL << 32)) return fail("at most 2^32 - 1 sites");
-    if (n == 0) return 0;
-    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
-    bounding_box(coords, n, lo, hi);
-    std::vector<int64_t> perm;
-    hilbert_order(coords, n, lo, hi, perm);
-    memcpy(perm_out, perm.data(), (size_t)n * sizeof(int64_t));
-    return 0;
-}
-
-extern "C" int ck_ref_distance(int metric, const double* A, const double* B, int64_t n, double* out) {
-    if (metric != CK_METRIC_HAVERSINE && metric != CK_METRIC_EUCLID) return fail("unknown metric");
-    if (n > 0 && (!A || !B || !out)) return fail("null array");
-    for (int64_t k = 0; k < n; ++k) out[k] = ref_distance(metric, A + 2 * k, B + 2 * k);
-    return 0;
-}
-
-// distance -> the monotone q the kernels compare (ck_vario.hip): squared chord of the unit vectors | squared distance
-static double vario_q_of_dist(int metric, double d) {
-    if (!(d >= 0.0)) return 0.0;
-    if (metric == CK_METRIC_EUCLID) return d * d;
-    const long double a = (long double)d / (2.0L * CK_EARTH_RADIUS_KM);
-    if (a >= 1.57079632679489661923L) return 4.0 + 1e-9;   // beyond half the circumference: everything
-    const long double sn = sinl(a);
-    return (double)(4.0L * sn * sn);
-}
-
-// Rounding band of q around a threshold: |q_device - q(d_reference)| stays far inside it.  Haversine: the unit
-// vectors carry ~1e-16 absolute error per component, so q = |u_i - u_j|^2 carries ~2 sqrt(q) 3e-16 (measured
-// 5e-16 sqrt(q) over lattice pairs from 5 km to 6 000 km), and the reference's own d a few ulp; Euclid: a few ulp.
-static double vario_band(int metric, double q) {
-    return metric == CK_METRIC_HAVERSINE ? 6e-15 * sqrt(q) + 8e-15 * q : 8e-15 * q;
-}
-
-// largest chord |u_i - u_j| of a pair with q <= qlim, with a safety margin (ck_vario.hip: tile culling)
-static double vario_cmax(double qlim) {
-    const double m = sqrt(qlim) * (1.0 + 1e-9) + 1e-12;
-    return m == m ? m : INFINITY;
 }
 
 extern "C" int ck_vario_begin(ck_handle* h, const double* coords_i, const double* resid_i, int64_t n_i,
@@ -1983,47 +1771,27 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
     *lo = *hi = NAN;
     *n_positive = 0;
     const int metric = h->metric;
-    const double qcap0 = vario_q_of_dist(metric, max_dist);
-    double cap = qcap0 + vario_band(metric, qcap0);   // pairs up to here may still have d <= max_dist
+    const double qcap0 = ck_host_vario_q_of_dist(metric, max_dist);
+    double cap = qcap0 + ck_host_vario_band(metric, qcap0);   // pairs up to here may still have d <= max_dist
     bool have_lo = false, have_hi = false;
     double best_lo = INFINITY, best_hi = -1.0;
     // Round 0 normally settles both extremes.  Further rounds only when every pair within the band of the largest
     // q <= cap turns out to lie beyond max_dist: the cap then moves below them.
-    // best_lo / best_hi over the candidates of one list
+    // best_lo / best_hi over the candidates of one list, by the reference's own arithmetic (ck_host.cpp)
     auto decide = [&](const std::vector<CkVarioPair>& cand) {
-        const int64_t nc = (int64_t)cand.size();
-        double tlo[8], thi[8];
-        for (int t = 0; t < 8; ++t) {
-            tlo[t] = INFINITY;
-            thi[t] = -1.0;
-        }
-        host_parallel(nc, [&](int t, int64_t a, int64_t b) {
-            double l = INFINITY, u = -1.0;
-            for (int64_t k = a; k < b; ++k) {
-                const double d = ref_distance(metric, &h->vg_ci[2 * (size_t)cand[k].i], &h->vg_cj[2 * (size_t)cand[k].j]);
-                if (d <= max_dist) {            // src/fields.py:212
-                    if (d > u) u = d;           // :395
-                    if (d > 0.0 && d < l) l = d;   // :394
-                }
-            }
-            tlo[t] = l;
-            thi[t] = u;
-        });
-        for (int t = 0; t < 8; ++t) {
-            if (thi[t] > best_hi) best_hi = thi[t];
-            if (tlo[t] < best_lo) best_lo = tlo[t];
-        }
+        ck_host_vario_decide_extent(metric, h->vg_ci.data(), h->vg_cj.data(), cand.data(), (int64_t)cand.size(), max_dist,
+                                    &best_lo, &best_hi);
         have_hi = best_hi >= 0.0;
         have_lo = best_lo < INFINITY;
     };
     for (int round = 0; round < 64 && !have_hi; ++round) {
         // The pass lists, on its way, every pair in a thin window under the cap: with dense data the largest retained q
         // lies inside it, and the candidates for the largest distance are then complete without a second pass.
-        const double win = fmax(1e-9 * cap, 8.0 * vario_band(metric, cap));
+        const double win = fmax(1e-9 * cap, 8.0 * ck_host_vario_band(metric, cap));
         const double qwin_lo = cap - win;
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         ck_launch_vario_extent(h->stream, h->vg_bgrid, h->vg_same, h->vg_iu, h->vg_ni, h->vg_ju, h->vg_nj, cap, h->vg_part,
-                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jbsub, vario_cmax(cap), h->vg_best, qwin_lo,
+                               h->rank, h->world, h->vg_ib64, h->vg_jb, h->vg_jbsub, ck_host_vario_cmax(cap), h->vg_best, qwin_lo,
                                h->vg_list, h->vg_count, h->vg_list_cap);
         HIPCHK(hipGetLastError());
         std::vector<CkVarioExt> part(h->vg_bgrid);
@@ -2044,8 +1812,8 @@ extern "C" int ck_vario_extent(ck_handle* h, double max_dist, double* lo, double
         }
         if (best.imax < 0) break;   // no pair with q <= cap at all
         // every pair whose q is within the band of an extreme is a candidate; the reference's formula decides
-        double qtop_lo = best.rmax - 2.0 * vario_band(metric, best.rmax);
-        const double qbot_hi = (!have_lo && best.imin >= 0) ? best.rmin + 2.0 * vario_band(metric, best.rmin) : -1.0;
+        double qtop_lo = best.rmax - 2.0 * ck_host_vario_band(metric, best.rmax);
+        const double qbot_hi = (!have_lo && best.imin >= 0) ? best.rmin + 2.0 * ck_host_vario_band(metric, best.rmin) : -1.0;
         bool top_done = false;
         if (!woverflow && qtop_lo >= qwin_lo) {   // the window holds every top candidate
             h->vg_stats[0] += (int64_t)wcand.size();
@@ -2092,56 +1860,13 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
     if (edges[0] != 0.0) return fail("first bin edge must be 0 (src/fields.py:402)");
     if (!(max_dist > 0.0)) return fail("max_dist must be positive");
     const int metric = h->metric;
-    // Levels 1 .. E in ascending order: the inner edges below the cap, then the cap.  A pair's bin is the number of
-    // levels it passes (d > threshold: pd.cut's right-closed intervals, src/fields.py:214-216); a pair that passes
-    // level E is not retained (d > max_dist, :212, or beyond the last edge, where pd.cut yields no bin).
-    const double dcap = fmin(max_dist, edges[nb]);
-    double dthr[CK_VG_MAXBINS + 2], xa[CK_VG_MAXBINS + 2], xb[CK_VG_MAXBINS + 2], tq[CK_VG_MAXBINS + 2];
-    int E = 0;
-    for (int e = 1; e < nb && edges[e] < dcap; ++e) dthr[++E] = edges[e];
-    dthr[++E] = dcap;
-    dthr[0] = xa[0] = xb[0] = tq[0] = 0.0;
-    double q_reach = 0.0;   // largest q that can still be inside the cap's band
-    for (int e = 1; e <= E; ++e) {
-        tq[e] = vario_q_of_dist(metric, dthr[e]);
-        if (!(tq[e] > 0.0)) return fail("variogram bin edge too close to zero");
-        // the binning kernel's monotone x (ck_vario.hip): Euclid x = q; haversine x = q / 2 - 1 from a dot product,
-        // which costs an absolute 1e-15 of q near x = -1 on top of the band of the difference form
-        const double bnd = vario_band(metric, tq[e]) + (metric == CK_METRIC_HAVERSINE ? 3e-15 : 0.0);
-        const double qa = tq[e] + bnd, qb = tq[e] - bnd;
-        if (metric == CK_METRIC_HAVERSINE) {
-            xa[e] = (double)(0.5L * (long double)qa - 1.0L);
-            xb[e] = (double)(0.5L * (long double)qb - 1.0L);
-        } else {
-            xa[e] = qa;
-            xb[e] = qb;
-        }
-        if (!(xb[e] < xa[e])) return fail("variogram bin edge below the resolution of the distances");
-        q_reach = qa;
-    }
-    // Levels whose bands overlap (bins narrower than the rounding of the distances: max_dist equal to the smallest lattice
-    // distance makes linspace(lo, hi) a few 1e-15 wide, and the reference then bins by the last bits of its distances)
-    // form ONE level for the device, with the union of their bands; every pair inside it goes to the host, which walks
-    // it up through the cluster's edges with the reference's distance.  Device bin k = passed k clusters = real bin
-    // clast[k].  A cluster of one level is the ordinary case.
-    int cfirst[CK_VG_MAXBINS + 2], clast[CK_VG_MAXBINS + 2];
-    double cxa[CK_VG_MAXBINS + 2], cxb[CK_VG_MAXBINS + 2], cthr[CK_VG_MAXBINS + 2];
-    int EC = 0;
-    cfirst[0] = clast[0] = 0;
-    cxa[0] = cxb[0] = cthr[0] = 0.0;
-    for (int e = 1; e <= E; ++e) {
-        if (EC >= 1 && !(xb[e] > cxa[EC])) {   // overlaps the cluster so far
-            clast[EC] = e;
-            cxa[EC] = xa[e];
-            cthr[EC] = -1.0;   // not a single threshold: the device lists the pair also for the Euclidean metric
-        } else {
-            ++EC;
-            cfirst[EC] = clast[EC] = e;
-            cxa[EC] = xa[e];
-            cxb[EC] = xb[e];
-            cthr[EC] = dthr[e];
-        }
-    }
+    // levels, their rounding bands and the clusters of levels whose bands overlap: ck_host.cpp
+    CkVarioLevels lv;
+    if (ck_host_vario_levels(metric, max_dist, edges, nb, &lv)) return -1;
+    const int E = lv.E, EC = lv.EC;
+    const double *cxa = lv.cxa, *cxb = lv.cxb, *cthr = lv.cthr;
+    const int* clast = lv.clast;
+    const double q_reach = lv.q_reach;
     double* d_xa = h->vg_out;
     double* d_xb = h->vg_out + (CK_VG_MAXBINS + 2);
     double* d_dthr = h->vg_out + 2 * (CK_VG_MAXBINS + 2);
@@ -2157,7 +1882,7 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
         HIPCHK(hipMemsetAsync(h->vg_count, 0, sizeof(unsigned), h->stream));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         ck_launch_vario_bin(h->stream, metric, h->vg_same, covariogram ? 1 : 0, h->vg_iu, h->vg_iv, h->vg_ni, h->vg_ju,
-                            h->vg_jv, h->vg_nj, EC, d_xa, d_xb, d_dthr, vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jbsub,
+                            h->vg_jv, h->vg_nj, EC, d_xa, d_xb, d_dthr, ck_host_vario_cmax(q_reach), h->vg_ib64, h->vg_jb, h->vg_jbsub,
                             h->vg_bgrid, h->vg_psum, h->vg_pcnt, h->vg_list, h->vg_count, h->vg_list_cap, h->rank, h->world,
                             EC, d_sums, d_cnt, d_args);
         HIPCHK(hipGetLastError());
@@ -2178,37 +1903,8 @@ extern "C" int ck_vario_bin(ck_handle* h, double max_dist, const double* edges, 
         cnt[clast[k]] = dcn[k];
     }
     // The pairs inside the band of a level (cluster) were binned below it; the reference's formula on libm decides.
-    if (!fix.empty()) {
-        const int64_t nf = (int64_t)fix.size();
-        std::vector<double> dsum((size_t)8 * (CK_VG_MAXBINS + 1), 0.0);
-        std::vector<long long> dcnt((size_t)8 * (CK_VG_MAXBINS + 1), 0);
-        host_parallel(nf, [&](int t, int64_t a, int64_t b) {
-            double* ds = &dsum[(size_t)t * (CK_VG_MAXBINS + 1)];
-            long long* dc = &dcnt[(size_t)t * (CK_VG_MAXBINS + 1)];
-            for (int64_t k = a; k < b; ++k) {
-                const CkVarioPair& p = fix[(size_t)k];
-                if (p.lev < 1 || p.lev > EC) continue;
-                const double d = ref_distance(metric, &h->vg_ci[2 * (size_t)p.i], &h->vg_cj[2 * (size_t)p.j]);
-                const int from = clast[p.lev - 1];   // where the device put it: below the cluster
-                int to = from;
-                for (int e = cfirst[p.lev]; e <= clast[p.lev] && d > dthr[e]; ++e) to = e;
-                if (to == from) continue;
-                const double va = h->vg_vi[(size_t)p.i], vb = h->vg_vj[(size_t)p.j];
-                const double cl = covariogram ? va * vb : 0.5 * ((va - vb) * (va - vb));   // src/fields.py:382-385
-                ds[from] -= cl;
-                dc[from] -= 1;
-                if (to < E) {   // above the cap: not retained
-                    ds[to] += cl;
-                    dc[to] += 1;
-                }
-            }
-        });
-        for (int t = 0; t < 8; ++t)
-            for (int b = 0; b < nb && b <= E; ++b) {
-                sm[(size_t)b] += dsum[(size_t)t * (CK_VG_MAXBINS + 1) + b];
-                cnt[b] += dcnt[(size_t)t * (CK_VG_MAXBINS + 1) + b];
-            }
-    }
+    ck_host_vario_fix(metric, h->vg_ci.data(), h->vg_cj.data(), h->vg_vi.data(), h->vg_vj.data(), fix.data(), (int64_t)fix.size(),
+                      lv, covariogram ? 1 : 0, sm.data(), cnt);
     for (int b = E; b < nb; ++b) {   // bins above the cap hold nothing
         sm[(size_t)b] = 0.0;
         cnt[b] = 0;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ck_host.h"
 #include "ck_math.h"
 
 #define CK_NB 512   // outer block column width (panel width)
@@ -123,11 +124,7 @@ struct CkVarioExt {
     double rmin, rmax;
     long long imin, jmin, imax, jmax;
 };
-// a pair the kernels leave to the host (indices in the order the device sees the points; lev: the level whose
-// band the pair lies in, 0 for the candidates of the extent pass)
-struct CkVarioPair {
-    int i, j, lev, pad;
-};
+// CkVarioPair (a pair the kernels leave to the host): ck_host.h
 void ck_launch_vario_prep(hipStream_t s, const double* coords, int64_t n, int metric, double* u0, double* u1,
                           double* u2);
 int ck_vario_bin_grid(int64_t ni, int64_t nj);   // workgroups of the three pair passes (wave tiles of 64 x 1024 points)

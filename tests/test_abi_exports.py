@@ -27,6 +27,16 @@ def test_header_symbols_all_exported_and_bound():
     assert L.ck_version() >= 100
 
 
+def test_library_exports_exactly_the_declared_c_symbols():
+    """Every unmangled `ck_*` symbol the shared object exports is declared in include/cokrige.h (the helpers of
+    csrc/ck_model.cpp / ck_host.cpp are linked with hidden visibility)."""
+    import subprocess
+    from sif_xco2_cokriging_amd import native
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("ck_")})
+    assert exported == declared_symbols()
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     from sif_xco2_cokriging_amd import native
