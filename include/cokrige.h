@@ -249,7 +249,10 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
  * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local);
- * [11] ck_verify_model (host wall clock, synchronised). */
+ * [11] ck_verify_model (host wall clock, synchronised); [12] how many times, so far, the safety-net launch behind a chained
+ * trailing update had to factor a panel's diagonal block itself (option "panel_chain"; expected 0); [13] the verdict of the
+ * stream-concurrency probe in front of the first chained update (1: the second stream runs beside the main one, -1: it
+ * does not and the chain is off, 0: not probed yet). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it
@@ -264,13 +267,17 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1/2) brackets every trailing-update launch with HIP events (2: the Sigma updates only, for
  * the step-wise form, where Sigma and right-hand-side updates alternate; read back through ck_timings);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
+ * "panel_chain" (0/1, default 1): the 512 x 512 diagonal block of the next panel is factored by one workgroup on a second
+ * stream UNDER the trailing update that completes it -- the ten tiles of that block signal a counter -- instead of by 24
+ * dependent launches behind it; "panel_fused" bit 3 (8): the same single-workgroup factorisation as a launch of its own
+ * (A/B: what it costs when nothing hides it);
  * "recv_slots" (2..64, default 2; before the first assemble / ck_estimate_bytes): receive buffers for remote panels of a
  * multi-process run -- 2 for the per-panel look-ahead schedule, 2 G for the grouped one (ck_panel_apply_group);
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
  * ck_factor / ck_predict;
- * "panel_fused" (0..3, default 2; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
+ * "panel_fused" (0..15, default 2; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
  * 64-column sub-blocks are processed left-looking with the update and the row solve fused into one launch;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);

@@ -1,0 +1,51 @@
+"""A/B of the panel step, variants INTERLEAVED (the clocks sag under sustained FP64 matrix load: a variant measured later
+in a process looks slower): 24 dependent launches per panel (rounds 1-2) | the diagonal block's factorisation as ONE
+workgroup launched on its own (panel_fused bit 3) | the same workgroup on a second stream UNDER the trailing update
+(panel_chain = 1), for several panel groupings.  Results must agree to rounding."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sif_xco2_cokriging_amd import native, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+which = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+pb = synth.conus_problem(n, seed=20003)
+pv = pb["params"]
+pc = pb["pcoords"][:2048]
+variants = [("base", {"panel_chain": 0}), ("own", {"panel_chain": 0, "panel_fused": 2 | 8}), ("chain", {"panel_chain": 1}),
+            ("chainG1", {"panel_chain": 1, "panel_group": 1}), ("chainG2", {"panel_chain": 1, "panel_group": 2}),
+            ("baseG1", {"panel_chain": 0, "panel_group": 1}), ("chainG4", {"panel_chain": 1, "panel_group": 4})]
+if which:
+    variants = [v for v in variants if v[0] in which]
+hs = []
+for name, opts in variants:
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(pb["metric"])
+    for k in range(2):
+        h.set_data(k, pb["coords"][k], pb["values"][k])
+    h.set_option("time_gemm", 1)
+    for k, v in opts.items():
+        h.set_option(k, v)
+    hs.append(h)
+fm = {name: [] for name, _ in variants}
+sy = {name: [] for name, _ in variants}
+for it in range(reps + 1):
+    for (name, _), h in zip(variants, hs):
+        h.assemble_joint()
+        assert h.factor() == 0
+        t = h.timings()
+        fm[name].append(t["factor_ms"])
+        sy[name].append(t["syrk_ms"])
+ref = None
+for (name, _), h in zip(variants, hs):
+    t = h.timings()
+    pred, err = h.predict(0, pc)
+    if ref is None:
+        ref = (pred, err)
+    dp = np.max(np.abs(pred - ref[0])) / np.max(np.abs(ref[0]))
+    de = np.max(np.abs(err - ref[1])) / np.max(np.abs(ref[1]))
+    print(f"N={2*n} {name:8s} factor_ms {' '.join(f'{x:.1f}' for x in fm[name])} | min {min(fm[name][1:]):.2f} | syrk_ms {' '.join(f'{x:.1f}' for x in sy[name][1:])} | "
+          f"diff pred {dp:.1e} err {de:.1e} | safety-net {t['chain_safety_net_runs']:.0f}, concurrent {t['chain_streams_concurrent']:.0f}", flush=True)
+    h.close()

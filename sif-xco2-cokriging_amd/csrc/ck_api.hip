@@ -158,7 +158,7 @@ struct ck_handle {
     int64_t vg_stats[4] = {0, 0, 0, 0};   // host-decided pairs of the extent pass | of the binning pass | pairs visited by
                                           // the binning pass | extra extent rounds
     // timings
-    double t_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double t_ms[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int time_gemm = 0;   // 1: bracket every trailing-update launch with events | 2: the Sigma updates only (step-wise form)
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
@@ -182,6 +182,19 @@ struct ck_handle {
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
     long long local_slab_doubles = 0; // costs up to seconds, erratically); grows when a call needs more
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
+    // option "panel_chain" (default 1): the 512 x 512 diagonal block of the next panel is factored by ONE workgroup on a
+    // second stream UNDER the trailing update that completes it (ck_la.hip, "chain"); the panel step behind the update is
+    // then one launch (the rows below the block)
+    int panel_chain = 0;   // measured (scripts/ab_chain.py, N = 40 000): 361.6 against 362.0 ms at G = 3 -- the chains of the in-group panels stay exposed --, 412 against 370 ms at G = 1: off
+    hipStream_t chain_stream = nullptr;
+    unsigned* d_chain = nullptr;          // [0] tiles counted, [1] sequence number of the last finished chain, [2] chains the
+                                          // safety net had to do, [3] / [4] flag / result of the concurrency probe
+    int chain_probed = 0;                 // 0: not yet | 1: the two streams run side by side | -1: they do not (chain off)
+    hipStream_t chain_probed_for = nullptr;
+    unsigned chain_target = 0, chain_seq = 0;
+    int chain_panel = -1;                 // the panel whose diagonal block a chain launch is taking care of
+    const double* chain_P = nullptr;      // ... and its storage (the Schur complement reuses panel numbers)
+    hipEvent_t ev_chain = nullptr;
 };
 
 extern "C" int ck_version(void) { return 100; }
@@ -237,6 +250,10 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
     }
+    HIPCHK(hipStreamCreateWithFlags(&h->chain_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void**)&h->d_chain, 8 * sizeof(unsigned)));
+    HIPCHK(hipMemset(h->d_chain, 0, 8 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&h->d_blk, 3 * sizeof(CkMatern)));
     HIPCHK(hipMalloc((void**)&h->d_info, sizeof(long long)));
     HIPCHK(hipMemset(h->d_info, 0, sizeof(long long)));
@@ -277,6 +294,12 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (auto e : h->ev_col) (void)hipEventDestroy(e);
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->chain_stream) {
+        (void)hipStreamSynchronize(h->chain_stream);
+        (void)hipStreamDestroy(h->chain_stream);
+    }
+    if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
+    if (h->d_chain) (void)hipFree(h->d_chain);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -641,6 +664,10 @@ static int64_t external_index(const ck_handle* h, int64_t g) { return g > h->n0p
 extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
+    if (h->chain_panel >= 0) {   // a chain of an abandoned sweep may still be writing its panel
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));
+        h->chain_panel = -1;
+    }
     HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     bool fast_done = false;
@@ -741,10 +768,63 @@ static void gemm_timed_collect(ck_handle* h, int slot) {
 
 // ---- the building blocks, on an explicit stream --------------------------------------------------
 // two-level panel step on block column K: 8 x (64 x 64 Cholesky, row solves, K = 64 update)
+// Trailing update of block columns J0, J0 + Jstep, ... by the panels K0 .. K0 + np - 1.  If J0 is the very next panel
+// (K0 + np == J0: its last update before it is factored) and owned here, the factorisation of its 512 x 512 diagonal block
+// is started on the second stream in front of the update (ck_la.hip, "chain"); panel_factor_on picks it up.
+static void syrk_update(ck_handle* h, hipStream_t st, int K0, int np, int J0, int Jstep, int nJ) {
+    if (nJ <= 0 || np <= 0) return;
+    unsigned* counter = nullptr;
+    const bool want = h->panel_chain && st == h->stream && K0 + np == J0 && J0 < h->nK && h->sig[J0] && h->chain_panel < 0;
+    if (want && (h->chain_probed == 0 || h->chain_probed_for != st)) {
+        // once per main stream: do the two streams run side by side?  (both are drained first: the probe must not sit
+        // behind queued work)
+        unsigned res = 0;
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(h->chain_stream);
+        (void)hipMemsetAsync(h->d_chain + 3, 0, 2 * sizeof(unsigned), st);
+        (void)hipStreamSynchronize(st);
+        ck_launch_chain_probe(h->chain_stream, st, h->d_chain + 3, h->d_chain + 4);
+        (void)hipStreamSynchronize(h->chain_stream);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(&res, h->d_chain + 4, sizeof(unsigned), hipMemcpyDeviceToHost);
+        h->chain_probed = res ? 1 : -1;
+        h->chain_probed_for = st;
+    }
+    if (want && h->chain_probed == 1) {
+        double* P = h->sig[J0];
+        const int64_t R = h->Npad - (int64_t)J0 * CK_NB;
+        h->chain_target += CK_CHAIN_TILES_PER_LAUNCH;
+        h->chain_seq += 1;
+        ck_launch_diag_chain(h->chain_stream, P, P + R * CK_NB, (int64_t)J0 * CK_NB, h->d_info, h->d_chain, h->chain_target,
+                             h->d_chain + 1, h->chain_seq, 1);
+        (void)hipEventRecord(h->ev_chain, h->chain_stream);
+        h->chain_panel = J0;
+        h->chain_P = P;
+        counter = h->d_chain;
+    }
+    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend, counter);
+}
+
 static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
     double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
+    if (h->chain_panel == K && h->chain_P == P) {
+        // the diagonal block is being (or has been) factored under the update that completed it: wait for that launch,
+        // run the safety net (a no-op on the device unless the chain gave up waiting), then ONE launch for the rows below
+        h->chain_panel = -1;
+        (void)hipStreamWaitEvent(st, h->ev_chain, 0);
+        ck_launch_diag_chain(st, P, tail, (int64_t)K * CK_NB, h->d_info, h->d_chain, h->chain_target, h->d_chain + 1,
+                             h->chain_seq, 0);
+        if (R > CK_NB) ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail);
+        return;
+    }
+    if (h->panel_fused & 8) {   // the chain as a launch of its own (A/B: what the chain costs when nothing hides it)
+        h->chain_seq += 1;
+        ck_launch_diag_chain(st, P, tail, (int64_t)K * CK_NB, h->d_info, h->d_chain, 0u, h->d_chain + 1, h->chain_seq, 0);
+        if (R > CK_NB) ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail);
+        return;
+    }
     if (h->panel_fused & 4) {
         // The 512 x 512 diagonal block first -- right-looking over its eight 64-column sub-blocks, on its own 512
         // rows only (small launches: 64 x 64 Cholesky + inverse, row solves, K = 64 update) -- then every row below
@@ -799,7 +879,7 @@ static void apply_sigma_on(ck_handle* h, int K, const double* P, int Jlo, int Jh
     const int nJ = (Jhi - J0) / h->world + 1;
     (void)P;   // the group kernel reads panel K through d_panelptr[K] (own storage or receive buffer)
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K, 1, J0, h->world, nJ, h->Npad, h->nend);
+    syrk_update(h, st, K, 1, J0, h->world, nJ);
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -908,7 +988,7 @@ extern "C" int ck_panel_apply_group(ck_handle* h, int K0, int np, int what, int 
             const int step = h->world * n_phase;
             const int nJ = (J_hi - J0) / step + 1;
             gemm_timed_begin(h);
-            ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, np, J0, step, nJ, h->Npad, h->nend);
+            syrk_update(h, h->stream, K0, np, J0, step, nJ);
             gemm_timed_end(h);
         }
     }
@@ -984,14 +1064,14 @@ static int factor_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, g, K0 + g, 1, 1, h->Npad, h->nend);
+                    syrk_update(h, h->stream, K0, g, K0 + g, 1, 1);
                     gemm_timed_end(h);
                 }
                 panel_factor_on(h, K0 + g, h->stream);
             }
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
-                ck_launch_syrk_group(h->stream, h->d_sigptr, h->d_panelptr, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc, h->Npad, h->nend);
+                syrk_update(h, h->stream, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc);
                 gemm_timed_end(h);
             }
         }
@@ -1068,6 +1148,12 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[1] = ms;
     gemm_timed_collect(h, 5);
+    {
+        unsigned w[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(w, h->d_chain, sizeof(w), hipMemcpyDeviceToHost));
+        h->t_ms[12] = (double)w[2];             // chains the safety net had to do so far (expected: 0)
+        h->t_ms[13] = (double)h->chain_probed;
+    }
     h->factored = true;
     return 0;
 }
@@ -2118,7 +2204,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "panel_fused")) {   // see ck_handle::panel_fused
-        if (value < 0 || value > 7) return fail("panel_fused must be in [0, 7]");
+        if (value < 0 || value > 15) return fail("panel_fused must be in [0, 15]");
         h->panel_fused = (int)value;
         return 0;
     }
@@ -2146,6 +2232,10 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
             h->aux_state = 0;
         }
         h->site_order = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "panel_chain")) {   // see ck_handle::panel_chain
+        h->panel_chain = value != 0;
         return 0;
     }
     if (!strcmp(name, "recv_slots")) {   // see ck_handle::recv_slots; before the first assemble / ck_estimate_bytes
@@ -2184,7 +2274,7 @@ extern "C" int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count) {
 
 extern "C" int ck_timings(ck_handle* h, double* out, int n) {
     CHKH(h);
-    for (int k = 0; k < n && k < 12; ++k) out[k] = h->t_ms[k];
+    for (int k = 0; k < n && k < 14; ++k) out[k] = h->t_ms[k];
     return 0;
 }
 

@@ -80,8 +80,18 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // Cholesky trailing update of every owned block column J = J0 + y * Jstep (y < nJ) by panel K
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
+// chain_counter != nullptr (ck_la.hip, "chain"): the ten lower tiles of the first block column's diagonal block bump it
+// after their stores -- a k_diag_chain launch on a second stream is waiting for them
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */);
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */,
+                          unsigned* chain_counter = nullptr);
+// the whole factorisation of a panel's 512 x 512 diagonal block in ONE workgroup: wait != 0: first wait (bounded) for
+// *counter to reach target; skipped on the device when *done == seq; publishes seq in *done
+#define CK_CHAIN_TILES_PER_LAUNCH 10
+void ck_launch_diag_chain(hipStream_t s, double* P, double* tail, int64_t g0, long long* info, const unsigned* counter,
+                          unsigned target, unsigned* done, unsigned seq, int wait);
+// *out = 1 iff a kernel waiting on `second` saw a flag set by a kernel launched afterwards on `mainst` (both must be idle)
+void ck_launch_chain_probe(hipStream_t second, hipStream_t mainst, unsigned* flag, unsigned* out);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ, int64_t mrows, int64_t nvalid);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur

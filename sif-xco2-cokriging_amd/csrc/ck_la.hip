@@ -483,10 +483,34 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// The panel's 512 x 512 diagonal block is factored UNDER the trailing update ("chain")
+// ---------------------------------------------------------------------------------------
+// A trailing update whose first block column J0 is the very next panel (K0 + np == J0) is the LAST update that column
+// receives before it is factored.  The factorisation of its 512 x 512 diagonal block -- eight 64 x 64 Cholesky steps with
+// their inverses, the row solves and left-looking updates inside the block: 24 dependent launches of 20 - 30 us on at most
+// eight workgroups when issued from the host, pure latency -- needs only the ten lower 128 x 128 tiles of that block to be
+// final.  Those ten tiles bump a counter after their stores; ONE workgroup on a second stream (k_diag_chain: submitted
+// BEFORE the update, so it is already resident when the update fills the chip -- a kernel submitted behind a resident
+// grid of this size starves until the grid drains) waits for the counter and runs the whole chain
+// on its own while the other ~10^4 tiles of the update keep the chip busy.  The host then only launches the row kernel
+// for the rows below the block (k_panel_rows_all) behind an event of the second stream.  The wait is bounded: if it
+// expires, `done` keeps its old value and the host's next launch on the main stream (the same kernel with wait = 0)
+// does the work.  Counter and sequence numbers are monotone over launches: nothing is reset between them.
+#define CK_CHAIN_TILES 10
+#define CK_CHAIN_LDS (2 * 64 * 66 * 8)   // the chain's two operand arrays (potrf64_body / lt_rows_body): 67 584 bytes
+
+// a dependency tile has stored its C tile (or has nothing to store): make it visible, count it
+__device__ __forceinline__ void chain_signal(unsigned* counter) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(counter, 1u);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d(double* const* __restrict__ sigptr,
                                                          double* const* __restrict__ srcptr, int K0, int np, int J0,
-                                                         int Jstep, long Npad, long nvalid) {
+                                                         int Jstep, long Npad, long nvalid, unsigned* chain_counter) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
@@ -497,11 +521,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (r0 + 127 < c0) return;
+    // one of the ten lower tiles of the first block column's diagonal block, which a chain is waiting for (uniform)
+    const bool dep = chain_counter != nullptr && blockIdx.y == 0 && r0 < CK_NB;
     // tiles entirely inside the identity padding behind the last site (up to 511 rows / columns): a padded row of L is
     // zero left of its diagonal, so their update is exactly zero
-    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) return;
+    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) {
+        if (dep) chain_signal(chain_counter);
+        return;
+    }
     const CkSrcSyrk src{srcptr, K0, J, r0, c0};
     gemm_tile_d<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
+    if (dep) chain_signal(chain_counter);
 }
 
 template <int WAVES>
@@ -563,11 +593,11 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the
 // block-column-cyclic stride of a multi-process run
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid) {
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid, unsigned* chain_counter) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid);
+    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid, chain_counter);
 }
 
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
@@ -1014,6 +1044,97 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const doub
         lt_rows_body<true>(X + row0 * CK_NB + 64 * j, X + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
                            tail + (long)j * 64 * 64, As, Bs);
     }
+}
+
+// The chain itself (256 threads): the 512 x 512 diagonal block at the top of panel P, left-looking over its eight 64-column
+// sub-blocks -- sub-block q: its diagonal block receives the updates of the sub-blocks before it, is factored and inverted
+// (potrf64_body), then every 64-row chunk below it inside the block is updated and solved (lt_rows_body).  Everything
+// lives in global memory (2 MB, L2 resident); what one phase stores the next reads after a workgroup fence + barrier.
+__device__ __forceinline__ void diag_chain_body(double* __restrict__ P, double* __restrict__ tail, long g0, long long* info,
+                                                char* lds) {
+    double (*M)[66] = reinterpret_cast<double (*)[66]>(lds);
+    double* As = reinterpret_cast<double*>(lds);
+    double* Bs = As + 64 * 66;
+#pragma unroll 1
+    for (int q = 0; q < CK_NB / 64; ++q) {
+        const int jb = 64 * q;
+        if (q > 0) {
+            lt_diag_update(P, CK_NB, 0, q, &M[0][0]);
+            __threadfence_block();
+            __syncthreads();
+        }
+        potrf64_body(P + (long)jb * CK_NB + jb, CK_NB, g0 + jb, info, tail + (long)q * 64 * 64, M, M);
+        __threadfence_block();
+        __syncthreads();
+#pragma unroll 1
+        for (int c = q + 1; c < CK_NB / 64; ++c) {
+            lt_rows_body<true>(P + (long)(64 * c) * CK_NB + jb, P + (long)(64 * c) * CK_NB, CK_NB, P + (long)jb * CK_NB, CK_NB, q,
+                               tail + (long)q * 64 * 64, As, Bs);
+            __syncthreads();   // As / Bs are reused by the next chunk
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// counter / target: wait (bounded) until the ten tiles of the update have been counted, 0 / nullptr: no wait;
+// done / seq: skip the work if *done == seq already (the main stream's safety-net launch), publish seq at the end
+__global__ __launch_bounds__(256) void k_diag_chain(double* __restrict__ P, double* __restrict__ tail, long g0,
+                                                     long long* info, const unsigned* counter, unsigned target,
+                                                     unsigned* done, unsigned seq, int wait) {
+    __shared__ __attribute__((aligned(16))) char lds[CK_CHAIN_LDS];
+    __shared__ int go;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+            ok = 0;             // already done by the launch on the second stream
+        } else if (wait) {
+            ok = 0;             // about 0.2 s at most; then the main stream's launch takes over
+            for (int spin = 0; spin < 400000; ++spin) {
+                const unsigned c = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(c - target) >= 0) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        go = ok;
+    }
+    __syncthreads();
+    if (!go) return;            // uniform
+    __threadfence();            // acquire: the tiles' stores (other CUs, other XCDs' L2s) are visible from here on
+    diag_chain_body(P, tail, g0, info, lds);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!wait && counter) atomicAdd(const_cast<unsigned*>(counter) + 2, 1u);   // word [2]: chains done by the safety net
+    }
+}
+
+// Do kernels of the second stream really run beside kernels of the main stream?  (HIP maps streams onto a few hardware
+// queues; two streams that share one are serialised, and a waiting chain would then sit in FRONT of the update it waits
+// for.)  k_chain_probe_wait is launched on the second stream, k_chain_probe_set afterwards on the main stream: out = 1
+// iff the waiter saw the flag within ~20 ms.
+__global__ void k_chain_probe_wait(const unsigned* flag, unsigned* out) {
+    unsigned seen = 0;
+    for (int spin = 0; spin < 20000 && !seen; ++spin) {
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(32);
+    }
+    *out = seen ? 1u : 0u;
+}
+__global__ void k_chain_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+void ck_launch_chain_probe(hipStream_t second, hipStream_t mainst, unsigned* flag, unsigned* out) {
+    k_chain_probe_wait<<<dim3(1), dim3(64), 0, second>>>(flag, out);
+    k_chain_probe_set<<<dim3(1), dim3(64), 0, mainst>>>(flag);
+}
+
+void ck_launch_diag_chain(hipStream_t s, double* P, double* tail, int64_t g0, long long* info, const unsigned* counter,
+                          unsigned target, unsigned* done, unsigned seq, int wait) {
+    k_diag_chain<<<dim3(1), dim3(256), 0, s>>>(P, tail, (long)g0, info, counter, target, done, seq, wait);
 }
 
 void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail) {

@@ -442,10 +442,11 @@ class Handle:
         return dict(tflops=out[0], shader_mhz=out[1], cycles_per_mfma_per_wave=out[2])
 
     def timings(self):
-        out = np.zeros(12)
-        _chk(lib().ck_timings(self._h, _p(out), 12))
+        out = np.zeros(14)
+        _chk(lib().ck_timings(self._h, _p(out), 14))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
-                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms"]
+                "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms",
+                "chain_safety_net_runs", "chain_streams_concurrent"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):
