@@ -235,6 +235,10 @@ int ck_debug_get_entries(ck_handle* h, const int64_t* rows_host, const int64_t* 
 /* perm_out[j] = caller's index (within process k) of the site at internal position j.  Identity
  * with option site_order = 0; a Hilbert-curve order with site_order = 1 (the default). */
 int ck_debug_site_order(ck_handle* h, int k, int64_t* perm_out, int64_t n_k);
+/* Phase profile of the 64 x 64 diagonal-block kernel (Cholesky + inverse, the latency-bound link of the panel chain):
+ * out8[0..5] = microseconds of load | factorisation | scaling + store | inverse of the diagonal 16 x 16 blocks |
+ * off-diagonal blocks of the inverse | store of the inverse; [6] / [7] = a whole launch (instrumented / product kernel). */
+int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8);
 /* Raw lane/register -> (row, col) map of v_mfma_f64_16x16x4_f64: out[64*4*3] ints (row, col, k-map check). */
 int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,
@@ -249,10 +253,9 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update
  * launches (k_syrk_panels) of the last ck_factor, [7]/[8] the same for the right-hand-side
  * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local);
- * [11] ck_verify_model (host wall clock, synchronised); [12] how many times, so far, the safety-net launch behind a chained
- * trailing update had to factor a panel's diagonal block itself (option "panel_chain"; expected 0); [13] the verdict of the
- * stream-concurrency probe in front of the first chained update (1: the second stream runs beside the main one, -1: it
- * does not and the chain is off, 0: not probed yet). */
+ * [11] ck_verify_model (host wall clock, synchronised); [12] 1 if the last ck_factor had to repeat the factorisation because
+ * a workgroup of the cooperative panel step (option "panel_fused" bit 4) timed out waiting for a pivot block (never
+ * observed; the bit is then off for the handle). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it
@@ -267,18 +270,20 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
 /* Options: "time_gemm" (0/1/2) brackets every trailing-update launch with HIP events (2: the Sigma updates only, for
  * the step-wise form, where Sigma and right-hand-side updates alternate; read back through ck_timings);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
- * "panel_chain" (0/1, default 1): the 512 x 512 diagonal block of the next panel is factored by one workgroup on a second
- * stream UNDER the trailing update that completes it -- the ten tiles of that block signal a counter -- instead of by 24
- * dependent launches behind it; "panel_fused" bit 3 (8): the same single-workgroup factorisation as a launch of its own
- * (A/B: what it costs when nothing hides it);
  * "recv_slots" (2..64, default 2; before the first assemble / ck_estimate_bytes): receive buffers for remote panels of a
  * multi-process run -- 2 for the per-panel look-ahead schedule, 2 G for the grouped one (ck_panel_apply_group);
  * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
  * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
  * ck_factor / ck_predict;
- * "panel_fused" (0..15, default 2; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
- * 64-column sub-blocks are processed left-looking with the update and the row solve fused into one launch;
+ * "panel_fused" (0..31, default 18 = 2 | 16; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
+ * 64-column sub-blocks are processed left-looking with the update and the row solve fused into one launch; bit 2: the
+ * 512 x 512 diagonal block first, then one launch for all rows below it; bit 4 (on by default): the WHOLE panel step of the
+ * factorisation -- eight 64 x 64 Cholesky factorisations with their inverses, the row solves, the panel-internal updates --
+ * in ONE launch of cooperating workgroups: workgroup b owns the 64-row chunk b of the panel and walks it through the
+ * sub-blocks as their pivot chunks are published through flags in device memory (agent-scope release / coherent loads,
+ * bounded waits), so that a chunk waits for the one chunk above it in the dependency chain instead of for 24 launch
+ * boundaries;
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
  * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by

@@ -1,7 +1,6 @@
 """A/B of the panel step, variants INTERLEAVED (the clocks sag under sustained FP64 matrix load: a variant measured later
-in a process looks slower): 24 dependent launches per panel (rounds 1-2) | the diagonal block's factorisation as ONE
-workgroup launched on its own (panel_fused bit 3) | the same workgroup on a second stream UNDER the trailing update
-(panel_chain = 1), for several panel groupings.  Results must agree to rounding."""
+in a process looks slower): 24 dependent launches per panel (rounds 1-2) against the cooperative single launch
+(k_panel_coop, option panel_fused bit 4), for several panel groupings.  Results must agree to rounding."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,9 +12,9 @@ which = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 pb = synth.conus_problem(n, seed=20003)
 pv = pb["params"]
 pc = pb["pcoords"][:2048]
-variants = [("base", {"panel_chain": 0}), ("own", {"panel_chain": 0, "panel_fused": 2 | 8}), ("chain", {"panel_chain": 1}),
-            ("chainG1", {"panel_chain": 1, "panel_group": 1}), ("chainG2", {"panel_chain": 1, "panel_group": 2}),
-            ("baseG1", {"panel_chain": 0, "panel_group": 1}), ("chainG4", {"panel_chain": 1, "panel_group": 4})]
+variants = [("launches", {"panel_fused": 2}), ("launchesG1", {"panel_fused": 2, "panel_group": 1}),
+            ("coop", {"panel_fused": 2 | 16}), ("coopG1", {"panel_fused": 2 | 16, "panel_group": 1}),
+            ("coopG2", {"panel_fused": 2 | 16, "panel_group": 2}), ("coopG4", {"panel_fused": 2 | 16, "panel_group": 4})]
 if which:
     variants = [v for v in variants if v[0] in which]
 hs = []
@@ -47,5 +46,5 @@ for (name, _), h in zip(variants, hs):
     dp = np.max(np.abs(pred - ref[0])) / np.max(np.abs(ref[0]))
     de = np.max(np.abs(err - ref[1])) / np.max(np.abs(ref[1]))
     print(f"N={2*n} {name:8s} factor_ms {' '.join(f'{x:.1f}' for x in fm[name])} | min {min(fm[name][1:]):.2f} | syrk_ms {' '.join(f'{x:.1f}' for x in sy[name][1:])} | "
-          f"diff pred {dp:.1e} err {de:.1e} | safety-net {t['chain_safety_net_runs']:.0f}, concurrent {t['chain_streams_concurrent']:.0f}", flush=True)
+          f"diff pred {dp:.1e} err {de:.1e} | redone {t['panel_coop_redone']:.0f}", flush=True)
     h.close()

@@ -174,27 +174,19 @@ struct ck_handle {
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     int local_tile_min = 64;     // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
-    int panel_fused = 2;              // option "panel_fused", bit 0: factorisation, bit 1: right-hand-side rows --
+    int panel_fused = 2 | 16;         // option "panel_fused", bit 0: factorisation, bit 1: right-hand-side rows --
                                       // left-looking 64-column sub-blocks inside a panel, fused launches (measured at
-                                      // N = 40 000: solve sweep 228.2 -> 219.6 ms, factorisation 362.9 -> 365.0 ms)
+                                      // N = 40 000: solve sweep 228.2 -> 219.6 ms, factorisation 362.9 -> 365.0 ms);
+                                      // bit 4: the whole panel step of the factorisation in one launch of cooperating
+                                      // workgroups (k_panel_coop: 360.4 -> 350.0 ms; N = 10 000: 14.4 -> 12.8 ms)
     int64_t loo_g0 = -1;              // >= 0 during ck_loocv: right-hand-side row 1 + p is the unit vector of site loo_g0 + p
     double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
     long long local_slab_doubles = 0; // costs up to seconds, erratically); grows when a call needs more
     bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
-    // option "panel_chain" (default 1): the 512 x 512 diagonal block of the next panel is factored by ONE workgroup on a
-    // second stream UNDER the trailing update that completes it (ck_la.hip, "chain"); the panel step behind the update is
-    // then one launch (the rows below the block)
-    int panel_chain = 0;   // measured (scripts/ab_chain.py, N = 40 000): 361.6 against 362.0 ms at G = 3 -- the chains of the in-group panels stay exposed --, 412 against 370 ms at G = 1: off
-    hipStream_t chain_stream = nullptr;
-    unsigned* d_chain = nullptr;          // [0] tiles counted, [1] sequence number of the last finished chain, [2] chains the
-                                          // safety net had to do, [3] / [4] flag / result of the concurrency probe
-    int chain_probed = 0;                 // 0: not yet | 1: the two streams run side by side | -1: they do not (chain off)
-    hipStream_t chain_probed_for = nullptr;
-    unsigned chain_target = 0, chain_seq = 0;
-    int chain_panel = -1;                 // the panel whose diagonal block a chain launch is taking care of
-    const double* chain_P = nullptr;      // ... and its storage (the Schur complement reuses panel numbers)
-    hipEvent_t ev_chain = nullptr;
+    // the cooperative panel step (ck_la.hip: k_panel_coop, option "panel_fused" bit 4): [0..15] its flags, [16] its error word
+    unsigned* d_coop = nullptr;
+    unsigned coop_seq = 0;
 };
 
 extern "C" int ck_version(void) { return 100; }
@@ -250,10 +242,8 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
     }
-    HIPCHK(hipStreamCreateWithFlags(&h->chain_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
-    HIPCHK(hipMalloc((void**)&h->d_chain, 8 * sizeof(unsigned)));
-    HIPCHK(hipMemset(h->d_chain, 0, 8 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&h->d_coop, 32 * sizeof(unsigned)));
+    HIPCHK(hipMemset(h->d_coop, 0, 32 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&h->d_blk, 3 * sizeof(CkMatern)));
     HIPCHK(hipMalloc((void**)&h->d_info, sizeof(long long)));
     HIPCHK(hipMemset(h->d_info, 0, sizeof(long long)));
@@ -294,12 +284,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (auto e : h->ev_col) (void)hipEventDestroy(e);
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->chain_stream) {
-        (void)hipStreamSynchronize(h->chain_stream);
-        (void)hipStreamDestroy(h->chain_stream);
-    }
-    if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
-    if (h->d_chain) (void)hipFree(h->d_chain);
+    if (h->d_coop) (void)hipFree(h->d_coop);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -664,10 +649,7 @@ static int64_t external_index(const ck_handle* h, int64_t g) { return g > h->n0p
 extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
-    if (h->chain_panel >= 0) {   // a chain of an abandoned sweep may still be writing its panel
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_chain, 0));
-        h->chain_panel = -1;
-    }
+
     HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     bool fast_done = false;
@@ -768,61 +750,19 @@ static void gemm_timed_collect(ck_handle* h, int slot) {
 
 // ---- the building blocks, on an explicit stream --------------------------------------------------
 // two-level panel step on block column K: 8 x (64 x 64 Cholesky, row solves, K = 64 update)
-// Trailing update of block columns J0, J0 + Jstep, ... by the panels K0 .. K0 + np - 1.  If J0 is the very next panel
-// (K0 + np == J0: its last update before it is factored) and owned here, the factorisation of its 512 x 512 diagonal block
-// is started on the second stream in front of the update (ck_la.hip, "chain"); panel_factor_on picks it up.
 static void syrk_update(ck_handle* h, hipStream_t st, int K0, int np, int J0, int Jstep, int nJ) {
-    if (nJ <= 0 || np <= 0) return;
-    unsigned* counter = nullptr;
-    const bool want = h->panel_chain && st == h->stream && K0 + np == J0 && J0 < h->nK && h->sig[J0] && h->chain_panel < 0;
-    if (want && (h->chain_probed == 0 || h->chain_probed_for != st)) {
-        // once per main stream: do the two streams run side by side?  (both are drained first: the probe must not sit
-        // behind queued work)
-        unsigned res = 0;
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamSynchronize(h->chain_stream);
-        (void)hipMemsetAsync(h->d_chain + 3, 0, 2 * sizeof(unsigned), st);
-        (void)hipStreamSynchronize(st);
-        ck_launch_chain_probe(h->chain_stream, st, h->d_chain + 3, h->d_chain + 4);
-        (void)hipStreamSynchronize(h->chain_stream);
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(&res, h->d_chain + 4, sizeof(unsigned), hipMemcpyDeviceToHost);
-        h->chain_probed = res ? 1 : -1;
-        h->chain_probed_for = st;
-    }
-    if (want && h->chain_probed == 1) {
-        double* P = h->sig[J0];
-        const int64_t R = h->Npad - (int64_t)J0 * CK_NB;
-        h->chain_target += CK_CHAIN_TILES_PER_LAUNCH;
-        h->chain_seq += 1;
-        ck_launch_diag_chain(h->chain_stream, P, P + R * CK_NB, (int64_t)J0 * CK_NB, h->d_info, h->d_chain, h->chain_target,
-                             h->d_chain + 1, h->chain_seq, 1);
-        (void)hipEventRecord(h->ev_chain, h->chain_stream);
-        h->chain_panel = J0;
-        h->chain_P = P;
-        counter = h->d_chain;
-    }
-    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend, counter);
+    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend);
 }
 
 static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
     double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
-    if (h->chain_panel == K && h->chain_P == P) {
-        // the diagonal block is being (or has been) factored under the update that completed it: wait for that launch,
-        // run the safety net (a no-op on the device unless the chain gave up waiting), then ONE launch for the rows below
-        h->chain_panel = -1;
-        (void)hipStreamWaitEvent(st, h->ev_chain, 0);
-        ck_launch_diag_chain(st, P, tail, (int64_t)K * CK_NB, h->d_info, h->d_chain, h->chain_target, h->d_chain + 1,
-                             h->chain_seq, 0);
-        if (R > CK_NB) ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail);
-        return;
-    }
-    if (h->panel_fused & 8) {   // the chain as a launch of its own (A/B: what the chain costs when nothing hides it)
-        h->chain_seq += 1;
-        ck_launch_diag_chain(st, P, tail, (int64_t)K * CK_NB, h->d_info, h->d_chain, 0u, h->d_chain + 1, h->chain_seq, 0);
-        if (R > CK_NB) ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail);
+    if (h->panel_fused & 16) {
+        // the whole panel step in ONE launch of cooperating workgroups (ck_la.hip: k_panel_coop): a chunk of rows waits for
+        // the one chunk above it in the chain instead of for 24 grid-wide launch boundaries
+        h->coop_seq += 1;
+        ck_launch_panel_coop(st, P, R, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16);
         return;
     }
     if (h->panel_fused & 4) {
@@ -1022,6 +962,15 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->world > 1 && (h->panel_fused & 16)) {   // step-wise form: a timed-out cooperative panel step is an error here
+        unsigned werr = 0;                         // (ck_factor repeats the factorisation instead)
+        HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+        if (werr != 0) {
+            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
+            h->panel_fused &= ~16;
+            return fail("cooperative panel step timed out waiting for a pivot block (option panel_fused bit 4 now off): sweep again");
+        }
+    }
     *info = external_index(h, (int64_t)v);   // pivots inside the identity padding cannot fail
     return 0;
 }
@@ -1149,10 +1098,23 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     h->t_ms[1] = ms;
     gemm_timed_collect(h, 5);
     {
-        unsigned w[3] = {0, 0, 0};
-        HIPCHK(hipMemcpy(w, h->d_chain, sizeof(w), hipMemcpyDeviceToHost));
-        h->t_ms[12] = (double)w[2];             // chains the safety net had to do so far (expected: 0)
-        h->t_ms[13] = (double)h->chain_probed;
+        unsigned werr = 0;
+        HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+        h->t_ms[12] = 0.0;
+        if (werr != 0) {
+            // a workgroup of k_panel_coop gave up waiting for a pivot block (bounded spin: ~2 s; never observed): the factor
+            // is not to be trusted.  The cooperative panel step is switched off for this handle and the factorisation
+            // repeated with one launch per dependency.
+            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
+            h->panel_fused &= ~16;
+            h->assembled = false;
+            if (ck_assemble_joint(h)) return -1;
+            if (factor_sweep(h)) return -1;
+            if (ck_factor_info(h, info)) return -1;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            h->t_ms[1] = ms;
+            h->t_ms[12] = 1.0;                  // visible in ck_timings
+        }
     }
     h->factored = true;
     return 0;
@@ -1457,6 +1419,13 @@ extern "C" int ck_verify_model(ck_handle* h, int64_t* info) {
         if (factor_sweep(h)) return -1;   // records ev1 at its end
         HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        unsigned werr = 0;
+        HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+        if (werr != 0) {
+            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
+            h->panel_fused &= ~16;
+            return fail("cooperative panel step timed out (option panel_fused bit 4 now off): call ck_predict and ck_verify_model again");
+        }
     }
     *info = (int64_t)v;   // 1-based index among the prediction sites in the library's internal order, 0 = positive definite
     h->t_ms[11] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -2109,6 +2078,56 @@ extern "C" int ck_debug_get_entries(ck_handle* h, const int64_t* rows, const int
     return 0;
 }
 
+// Phase profile of the 64 x 64 diagonal-block kernel on a well-conditioned block: out[0..5] = microseconds of
+// load | factorisation | scaling + store | inverse of the diagonal 16 x 16 blocks | off-diagonal blocks | store of the
+// inverse (shader clock / 100 MHz reference), out[6] = the whole kernel by HIP events, out[7] = the same for the product
+// kernel (k_potrf64), average over `iters` back-to-back launches.
+extern "C" int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8) {
+    CHKH(h);
+    if (!out8 || iters < 1) return fail("bad arguments");
+    DevTemps tmp;
+    double *dA = nullptr, *dL = nullptr;
+    long long *dprof = nullptr, *dinfo = nullptr;
+    HIPCHK(tmp.get(&dA, 64 * 512 * 8));
+    HIPCHK(tmp.get(&dL, 64 * 64 * 8));
+    HIPCHK(tmp.get(&dprof, 16 * 8));
+    HIPCHK(tmp.get(&dinfo, 8));
+    std::vector<double> A((size_t)64 * 512, 0.0);
+    for (int i = 0; i < 64; ++i)
+        for (int j = 0; j <= i; ++j) A[(size_t)i * 512 + j] = (i == j ? 70.0 : 0.0) + 1.0 / (1.0 + i + j);
+    HIPCHK(hipMemsetAsync(dinfo, 0, 8, h->stream));
+    HIPCHK(hipMemsetAsync(dprof, 0, 16 * 8, h->stream));
+    double clk_mhz = 100.0;   // s_memtime counts the 100 MHz reference clock on gfx9
+    long long hp[16];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < 4; ++it) {
+        HIPCHK(hipMemcpyAsync(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+        ck_launch_potrf64_prof(h->stream, dA, 512, dinfo, dL, dprof);
+        HIPCHK(hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (it)
+            for (int k = 0; k < 6; ++k) acc[k] += (double)(hp[k + 1] - hp[k]) / clk_mhz / 3.0;
+    }
+    for (int k = 0; k < 6; ++k) out8[k] = acc[k];
+    for (int which = 0; which < 2; ++which) {
+        HIPCHK(hipMemcpyAsync(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (int it = 0; it < iters; ++it) {   // refactoring the factor is harmless for timing (it stays positive definite enough)
+            if (which == 0)
+                ck_launch_potrf64_prof(h->stream, dA, 512, dinfo, dL, dprof);
+            else
+                ck_launch_potrf64(h->stream, dA, 512, 0, dinfo, dL);
+        }
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        out8[6 + which] = (double)ms * 1e3 / iters;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
     CHKH(h);
     int32_t* d = nullptr;
@@ -2204,7 +2223,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "panel_fused")) {   // see ck_handle::panel_fused
-        if (value < 0 || value > 15) return fail("panel_fused must be in [0, 15]");
+        if (value < 0 || value > 31) return fail("panel_fused must be in [0, 31]");
         h->panel_fused = (int)value;
         return 0;
     }
@@ -2232,10 +2251,6 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
             h->aux_state = 0;
         }
         h->site_order = value != 0;
-        return 0;
-    }
-    if (!strcmp(name, "panel_chain")) {   // see ck_handle::panel_chain
-        h->panel_chain = value != 0;
         return 0;
     }
     if (!strcmp(name, "recv_slots")) {   // see ck_handle::recv_slots; before the first assemble / ck_estimate_bytes

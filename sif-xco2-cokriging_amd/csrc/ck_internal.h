@@ -80,18 +80,12 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // Cholesky trailing update of every owned block column J = J0 + y * Jstep (y < nJ) by panel K
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
-// chain_counter != nullptr (ck_la.hip, "chain"): the ten lower tiles of the first block column's diagonal block bump it
-// after their stores -- a k_diag_chain launch on a second stream is waiting for them
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */,
-                          unsigned* chain_counter = nullptr);
-// the whole factorisation of a panel's 512 x 512 diagonal block in ONE workgroup: wait != 0: first wait (bounded) for
-// *counter to reach target; skipped on the device when *done == seq; publishes seq in *done
-#define CK_CHAIN_TILES_PER_LAUNCH 10
-void ck_launch_diag_chain(hipStream_t s, double* P, double* tail, int64_t g0, long long* info, const unsigned* counter,
-                          unsigned target, unsigned* done, unsigned seq, int wait);
-// *out = 1 iff a kernel waiting on `second` saw a flag set by a kernel launched afterwards on `mainst` (both must be idle)
-void ck_launch_chain_probe(hipStream_t second, hipStream_t mainst, unsigned* flag, unsigned* out);
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */);
+// the whole panel step (diagonal blocks, inverses, row solves, panel-internal updates) in ONE launch: nrows / 64 workgroups
+// that hand each other the pivot blocks through flags[0..7] == seq (ck_la.hip: k_panel_coop); *err != 0: a wait timed out
+void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,
+                          unsigned seq, unsigned* err);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ, int64_t mrows, int64_t nvalid);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur
@@ -102,6 +96,8 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
 // the first non-positive pivot (only if still 0).
 void ck_launch_potrf64(hipStream_t s, double* A, int64_t ld, int64_t global_index0, long long* info_dev,
                        double* Linv);
+// diagnostic: the same with shader-clock stamps at its phase boundaries (prof: 16 words)
+void ck_launch_potrf64_prof(hipStream_t s, double* A, int64_t ld, long long* info, double* Linv, long long* prof);
 // X L^T = A in place for `nrows` rows of A (ld), 64 columns; L (64 x 64 lower, ldl).  nrows % 64 == 0.
 // fused panel step (ck_la.hip, option "panel_fused")
 void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv);

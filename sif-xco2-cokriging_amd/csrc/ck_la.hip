@@ -483,34 +483,10 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         }
 }
 
-// ---------------------------------------------------------------------------------------
-// The panel's 512 x 512 diagonal block is factored UNDER the trailing update ("chain")
-// ---------------------------------------------------------------------------------------
-// A trailing update whose first block column J0 is the very next panel (K0 + np == J0) is the LAST update that column
-// receives before it is factored.  The factorisation of its 512 x 512 diagonal block -- eight 64 x 64 Cholesky steps with
-// their inverses, the row solves and left-looking updates inside the block: 24 dependent launches of 20 - 30 us on at most
-// eight workgroups when issued from the host, pure latency -- needs only the ten lower 128 x 128 tiles of that block to be
-// final.  Those ten tiles bump a counter after their stores; ONE workgroup on a second stream (k_diag_chain: submitted
-// BEFORE the update, so it is already resident when the update fills the chip -- a kernel submitted behind a resident
-// grid of this size starves until the grid drains) waits for the counter and runs the whole chain
-// on its own while the other ~10^4 tiles of the update keep the chip busy.  The host then only launches the row kernel
-// for the rows below the block (k_panel_rows_all) behind an event of the second stream.  The wait is bounded: if it
-// expires, `done` keeps its old value and the host's next launch on the main stream (the same kernel with wait = 0)
-// does the work.  Counter and sequence numbers are monotone over launches: nothing is reset between them.
-#define CK_CHAIN_TILES 10
-#define CK_CHAIN_LDS (2 * 64 * 66 * 8)   // the chain's two operand arrays (potrf64_body / lt_rows_body): 67 584 bytes
-
-// a dependency tile has stored its C tile (or has nothing to store): make it visible, count it
-__device__ __forceinline__ void chain_signal(unsigned* counter) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(counter, 1u);
-}
-
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d(double* const* __restrict__ sigptr,
                                                          double* const* __restrict__ srcptr, int K0, int np, int J0,
-                                                         int Jstep, long Npad, long nvalid, unsigned* chain_counter) {
+                                                         int Jstep, long Npad, long nvalid) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y * Jstep;
     const long M = Npad - (long)J * CK_NB;
@@ -521,17 +497,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if (r0 + 127 < c0) return;
-    // one of the ten lower tiles of the first block column's diagonal block, which a chain is waiting for (uniform)
-    const bool dep = chain_counter != nullptr && blockIdx.y == 0 && r0 < CK_NB;
     // tiles entirely inside the identity padding behind the last site (up to 511 rows / columns): a padded row of L is
     // zero left of its diagonal, so their update is exactly zero
-    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) {
-        if (dep) chain_signal(chain_counter);
-        return;
-    }
+    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) return;
     const CkSrcSyrk src{srcptr, K0, J, r0, c0};
     gemm_tile_d<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
-    if (dep) chain_signal(chain_counter);
 }
 
 template <int WAVES>
@@ -593,11 +563,11 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the
 // block-column-cyclic stride of a multi-process run
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid, unsigned* chain_counter) {
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid) {
     if (nJ <= 0 || np <= 0) return;
     const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
     const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid, chain_counter);
+    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid);
 }
 
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
@@ -658,63 +628,111 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // operations applied to an identity -- 35 us.)
 // Linv: 64 x 64 row-major, lower triangle, upper zero.
 // Lt, Wi: two 64 x 66 LDS arrays (Lt[c][i] = L[i][c]; Wi = the inverse, row-major) owned by the calling kernel
+#define CK_POTRF_MARK(k)                                                            \
+    if (PROF) {                                                                     \
+        __syncthreads();                                                            \
+        if (threadIdx.x == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime();    \
+    }
+// PROF (diagnostic build of the kernel only: ck_debug_potrf_profile): shader-clock stamps at the phase boundaries
+template <bool PROF = false>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, long g0, long long* info,
-                                             double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66]) {
-    __shared__ double col[2][64];
+                                             double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66],
+                                             long long* prof = nullptr) {
+    __shared__ __attribute__((aligned(16))) double pan[2][4][68];   // the current block column, column-major (+ padding)
     __shared__ double pv[64];
     __shared__ double rdiag[64];
+    double* const col0 = &pan[0][0][0];   // 64 doubles of scratch for the scaling pass below
     const int t = threadIdx.x, bi = t >> 4, bk = t & 15;
     const bool lower = bk <= bi;
     double a[4][4];
+    CK_POTRF_MARK(0)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[r][c] = lower ? A[(long)(4 * bi + r) * ld + 4 * bk + c] : 0.0;
-    bool failed = false;
+    if (PROF) {
+        double sum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sum += a[r][c];
+        if (sum == 1.2345e300) prof[15] = 1;   // the loads have landed
+    }
+    CK_POTRF_MARK(1)
+    // Four columns per barrier: the owners of block column jb publish their 4 x 4 blocks (a 64 x 4 panel); every thread
+    // that still has work eliminates the panel's four columns ON ITS OWN COPIES of the three pieces it needs -- the
+    // 4 x 4 diagonal block D, the rows of its block row (Pi) and of its block column (Pk) -- and applies the four rank-1
+    // updates to its block.  The redundant in-register elimination (48 FMAs, 4 reciprocals) costs less than the three
+    // LDS round trips and barriers it replaces: 64 dependent steps become 16 (23 -> 12 us for the factorisation).
+    // As before the columns stay UNSCALED (a[i][k] -= a[i][j] a[k][j] / a[j][j]); L[i][j] = a[i][j] / sqrt(a[j][j]) once
+    // at the end.  Entries above the diagonal inside diagonal blocks carry garbage and are never used.
     for (int jb = 0; jb < 16; ++jb) {
+        double (*pb)[68] = pan[jb & 1];
+        if (bk == jb && bi >= jb) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * jb + jj;
-            double* cb = col[jj & 1];
-            if (bk == jb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cb[4 * bi + r] = a[r][jj];
+            for (int c = 0; c < 4; ++c) {
+                d2_t v0 = {a[0][c], a[1][c]}, v1 = {a[2][c], a[3][c]};
+                *reinterpret_cast<d2_t*>(&pb[c][4 * bi]) = v0;
+                *reinterpret_cast<d2_t*>(&pb[c][4 * bi + 2]) = v1;
             }
-            __syncthreads();
-            const double piv = cb[j];
-            if (t == 0) {
-                pv[j] = piv;
-                if (!failed && !(piv > 0.0)) {
-                    failed = true;
-                    atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + j + 1));
+        }
+        __syncthreads();
+        if (lower && bk >= jb) {
+            double D[4][4], Pi[4][4], Pk[4][4], rp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const d2_t d0 = *reinterpret_cast<const d2_t*>(&pb[c][4 * jb]), d1 = *reinterpret_cast<const d2_t*>(&pb[c][4 * jb + 2]);
+                const d2_t p0 = *reinterpret_cast<const d2_t*>(&pb[c][4 * bi]), p1 = *reinterpret_cast<const d2_t*>(&pb[c][4 * bi + 2]);
+                const d2_t k0 = *reinterpret_cast<const d2_t*>(&pb[c][4 * bk]), k1 = *reinterpret_cast<const d2_t*>(&pb[c][4 * bk + 2]);
+                D[0][c] = d0[0]; D[1][c] = d0[1]; D[2][c] = d1[0]; D[3][c] = d1[1];
+                Pi[0][c] = p0[0]; Pi[1][c] = p0[1]; Pi[2][c] = p1[0]; Pi[3][c] = p1[1];
+                Pk[0][c] = k0[0]; Pk[1][c] = k0[1]; Pk[2][c] = k1[0]; Pk[3][c] = k1[1];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double piv = D[jj][jj];
+                if (t == 17 * jb) {     // the diagonal block's owner records the pivots
+                    pv[4 * jb + jj] = piv;
+                    if (!(piv > 0.0)) atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + 4 * jb + jj + 1));
+                }
+                // 1 / piv sits on the critical path: v_rcp_f64 and two Newton steps instead of the IEEE division
+                double r0 = __builtin_amdgcn_rcp(piv);
+                r0 = fma(fma(-piv, r0, 1.0), r0, r0);
+                r0 = fma(fma(-piv, r0, 1.0), r0, r0);
+                rp[jj] = r0;
+#pragma unroll
+                for (int c2 = jj + 1; c2 < 4; ++c2) {
+                    const double f = D[c2][jj] * r0;
+#pragma unroll
+                    for (int r2 = c2; r2 < 4; ++r2) D[r2][c2] = fma(-D[r2][jj], f, D[r2][c2]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Pi[r][c2] = fma(-Pi[r][jj], f, Pi[r][c2]);
+                        Pk[r][c2] = fma(-Pk[r][jj], f, Pk[r][c2]);
+                    }
                 }
             }
-            if (lower && bk >= jb) {
-                // 1 / piv sits on the critical path of every step: v_rcp_f64 and two Newton steps (full precision up to the last
-                // bit or two) instead of the ~10 dependent instructions of the IEEE division: -1.8 us per call.  (Also tried:
-                // software-pipelining the column loop -- next column updated and published first, barrier, then the step's
-                // other 12 FMAs under the next LDS round trip: correct, +4.7 us, the extra predicates cost more than the FMAs.)
-                double rp = __builtin_amdgcn_rcp(piv);
-                rp = fma(fma(-piv, rp, 1.0), rp, rp);
-                rp = fma(fma(-piv, rp, 1.0), rp, rp);
-                double li[4], lk[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) li[r] = cb[4 * bi + r] * rp;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) lk[c] = cb[4 * bk + c];
+            if (bk == jb) {             // the owners' blocks ARE the panel: keep the eliminated columns
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bool upd = (bk > jb || c > jj) && (4 * bk + c <= 4 * bi + r);
-                        if (upd) a[r][c] -= li[r] * lk[c];
+                    for (int c = 0; c < 4; ++c) a[r][c] = Pi[r][c];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double li = Pi[r][jj] * rp[jj];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[r][c] = fma(-li, Pk[c][jj], a[r][c]);
                     }
             }
         }
     }
+    CK_POTRF_MARK(2)
     __syncthreads();
     // D^-1/2 once per index (not a sqrt and a division per element)
-    double* rs = col[0];
+    double* rs = col0;
     if (t < 64) {
         const double d = sqrt(pv[t]);
         rs[t] = 1.0 / d;
@@ -734,6 +752,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
                 }
             }
     }
+    CK_POTRF_MARK(3)
     __syncthreads();
     if (!Linv) return;   // uniform: a diagonal block with no rows below it (the last block of a local system)
     // ---- the inverse, blocked 4 x 4 in 16 x 16 blocks ----
@@ -760,6 +779,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
             for (int i = 0; i < 16; ++i) Wi[o + i][o + li] = x[i];
         }
     }
+    CK_POTRF_MARK(4)
     __syncthreads();
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
@@ -780,11 +800,26 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
         }
         __syncthreads();
     }
+    CK_POTRF_MARK(5)
     // out: 64 x 64 row-major, the blocks above the diagonal are zero
     for (int idx = t; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
         Linv[idx] = ((c >> 4) <= (r >> 4)) ? Wi[r][c] : 0.0;
     }
+    CK_POTRF_MARK(6)
+}
+
+// diagnostic: the same kernel with phase stamps (prof[0..6]: start | block loaded | factored | scaled + stored |
+// inverse: diagonal blocks | inverse: off-diagonal blocks | inverse stored), shader clock
+__global__ __launch_bounds__(256) void k_potrf64_prof(double* __restrict__ A, long ld, long long* info, double* __restrict__ Linv,
+                                                       long long* prof) {
+    __shared__ __attribute__((aligned(16))) double Lt[64][66];
+    __shared__ __attribute__((aligned(16))) double Wi[64][66];
+    potrf64_body<true>(A, ld, 0, info, Linv, Lt, Wi, prof);
+}
+
+void ck_launch_potrf64_prof(hipStream_t s, double* A, int64_t ld, long long* info, double* Linv, long long* prof) {
+    k_potrf64_prof<<<dim3(1), dim3(256), 0, s>>>(A, ld, info, Linv, prof);
 }
 
 __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ A, long ld, long g0, long long* info,
@@ -858,7 +893,14 @@ void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const
 // As, Bs: 64 x 66 doubles of LDS each.
 // C: the chunk (64 x 64, leading dimension ld); Ar: the chunk's rows, first of the 64 i earlier columns (same ld);
 // Br: the 64 rows of the block's own diagonal range, same columns (leading dimension ldb).
-template <bool SOLVE>
+// COH: Br and Linv were written by OTHER workgroups of the same launch (k_panel_coop): they are read with agent-scope
+// coherent loads (sc1: served from the coherence point, not from this XCD's possibly stale L2 lines)
+template <bool COH>
+__device__ __forceinline__ double ld_shared_result(const double* p) {
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+template <bool SOLVE, bool COH = false>
 __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const double* __restrict__ Ar, long ld,
                                              const double* __restrict__ Br, long ldb, int i,
                                              const double* __restrict__ Linv, double* As, double* Bs) {
@@ -870,7 +912,7 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
-            rb[u] = Br[(long)(sr + 4 * u) * ldb + sc];
+            rb[u] = ld_shared_result<COH>(Br + (long)(sr + 4 * u) * ldb + sc);
         }
     }
     d4_t cn[4];
@@ -889,11 +931,11 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
-                rb[u] = Br[(long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc];
+                rb[u] = ld_shared_result<COH>(Br + (long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc);
             }
         } else if (SOLVE) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) rb[u] = Linv[(sr + 4 * u) * 64 + sc];
+            for (int u = 0; u < 16; ++u) rb[u] = ld_shared_result<COH>(Linv + (sr + 4 * u) * 64 + sc);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
@@ -913,7 +955,7 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
     }
     if (i == 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) rb[u] = Linv[(sr + 4 * u) * 64 + sc];
+        for (int u = 0; u < 16; ++u) rb[u] = ld_shared_result<COH>(Linv + (sr + 4 * u) * 64 + sc);
     }
     // the updated chunk becomes the A operand (each wave re-reads only the 16 rows it wrote), Linv the B operand
 #pragma unroll
@@ -1046,95 +1088,210 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const doub
     }
 }
 
-// The chain itself (256 threads): the 512 x 512 diagonal block at the top of panel P, left-looking over its eight 64-column
-// sub-blocks -- sub-block q: its diagonal block receives the updates of the sub-blocks before it, is factored and inverted
-// (potrf64_body), then every 64-row chunk below it inside the block is updated and solved (lt_rows_body).  Everything
-// lives in global memory (2 MB, L2 resident); what one phase stores the next reads after a workgroup fence + barrier.
-__device__ __forceinline__ void diag_chain_body(double* __restrict__ P, double* __restrict__ tail, long g0, long long* info,
-                                                char* lds) {
-    double (*M)[66] = reinterpret_cast<double (*)[66]>(lds);
-    double* As = reinterpret_cast<double*>(lds);
-    double* Bs = As + 64 * 66;
-#pragma unroll 1
-    for (int q = 0; q < CK_NB / 64; ++q) {
-        const int jb = 64 * q;
-        if (q > 0) {
-            lt_diag_update(P, CK_NB, 0, q, &M[0][0]);
-            __threadfence_block();
-            __syncthreads();
+// ---------------------------------------------------------------------------------------
+// The whole panel step in ONE launch: k_panel_coop
+// ---------------------------------------------------------------------------------------
+// Workgroup b owns the 64-row chunk b of the panel and walks it left to right through the eight 64-column sub-blocks:
+// sub-block j as soon as chunk j -- whose diagonal block IS the pivot block of sub-block j -- has been published
+// (its rows solved, its diagonal block factored and inverted): flag[j] == seq.  The workgroups 0 .. 7 (the chunks inside
+// the 512 x 512 diagonal block; dispatched first, so always resident) finish with their own diagonal block: update by
+// their solved rows, potrf64_body, release fence, flag.  Everything else that 24 dependent launches per panel did --
+// 8 x (64 x 64 Cholesky + inverse, row solves, K = 64 update), each waiting for the whole previous one -- happens inside
+// this launch with only the true dependencies: a chunk waits for the ONE chunk above it in the chain, not for a
+// grid-wide barrier.  What crosses workgroups (the pivot chunk's rows and its inverse) is read with agent-scope
+// coherent loads; waits are bounded (a timeout sets *err, the host then repeats the factorisation the old way).
+#define CK_COOP_SPINS 2000000
+__device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, unsigned* err) {
+    __shared__ int ok_s;
+    __syncthreads();            // the previous use of ok_s has been read by everybody
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < CK_COOP_SPINS; ++spin) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
         }
-        potrf64_body(P + (long)jb * CK_NB + jb, CK_NB, g0 + jb, info, tail + (long)q * 64 * 64, M, M);
-        __threadfence_block();
-        __syncthreads();
-#pragma unroll 1
-        for (int c = q + 1; c < CK_NB / 64; ++c) {
-            lt_rows_body<true>(P + (long)(64 * c) * CK_NB + jb, P + (long)(64 * c) * CK_NB, CK_NB, P + (long)jb * CK_NB, CK_NB, q,
-                               tail + (long)q * 64 * 64, As, Bs);
-            __syncthreads();   // As / Bs are reused by the next chunk
-        }
-        __threadfence_block();
-        __syncthreads();
+        if (!ok) atomicOr(err, 1u);
+        ok_s = ok;
     }
+    __syncthreads();
+    return ok_s != 0;
 }
 
-// counter / target: wait (bounded) until the ten tiles of the update have been counted, 0 / nullptr: no wait;
-// done / seq: skip the work if *done == seq already (the main stream's safety-net launch), publish seq at the end
-__global__ __launch_bounds__(256) void k_diag_chain(double* __restrict__ P, double* __restrict__ tail, long g0,
-                                                     long long* info, const unsigned* counter, unsigned target,
-                                                     unsigned* done, unsigned seq, int wait) {
-    __shared__ __attribute__((aligned(16))) char lds[CK_CHAIN_LDS];
-    __shared__ int go;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
-            ok = 0;             // already done by the launch on the second stream
-        } else if (wait) {
-            ok = 0;             // about 0.2 s at most; then the main stream's launch takes over
-            for (int spin = 0; spin < 400000; ++spin) {
-                const unsigned c = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(c - target) >= 0) {
-                    ok = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(16);
+// The two halves of lt_rows_body for the chunk that is next in the chain (its pivot block is being factored right now):
+//   coop_accumulate  cn = C - sum_{ks < i} A_ks B_ks^T, everything that does not need the pivot block's inverse -- runs
+//                    while the pivot chunk's workgroup is still inside potrf64_body;
+//   coop_finish      X = cn Linv^T once the inverse is published; X goes to memory AND stays in Xs (LDS, 64 x 66) for
+//                    the last slab of the chunk's own diagonal update.
+__device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __restrict__ C, const double* __restrict__ Ar,
+                                                long ld, const double* __restrict__ Br, long ldb, int i, double* As,
+                                                double* Bs) {
+    constexpr int PITCH = 66;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int sr = tid >> 6, sc = tid & 63;
+    double ra[16], rb[16];
+    if (i > 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
+            rb[u] = ld_shared_result<true>(Br + (long)(sr + 4 * u) * ldb + sc);
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cn[jt][r] = C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li];
+    for (int ks = 0; ks < i; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            As[(sr + 4 * u) * PITCH + sc] = -ra[u];
+            Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+        }
+        __syncthreads();
+        if (ks + 1 < i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
+                rb[u] = ld_shared_result<true>(Br + (long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc);
             }
         }
-        go = ok;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const double av = As[(16 * w + li) * PITCH + 4 * s2 + g];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                cn[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[(16 * jt + li) * PITCH + 4 * s2 + g], cn[jt], 0, 0, 0);
+        }
+        __syncthreads();
     }
+}
+
+__device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restrict__ C, long ld,
+                                            const double* __restrict__ Linv, double* Xs, double* Bs) {
+    constexpr int PITCH = 66;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int sr = tid >> 6, sc = tid & 63;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Bs[(sr + 4 * u) * PITCH + sc] = ld_shared_result<true>(Linv + (sr + 4 * u) * 64 + sc);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(16 * w + g + 4 * r) * PITCH + 16 * jt + li] = cn[jt][r];
     __syncthreads();
-    if (!go) return;            // uniform
-    __threadfence();            // acquire: the tiles' stores (other CUs, other XCDs' L2s) are visible from here on
-    diag_chain_body(P, tail, g0, info, lds);
-    __threadfence();
+    d4_t x[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 4 * (jt + 1); ++s2)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * w + li) * PITCH + 4 * s2 + g], Bs[(16 * jt + li) * PITCH + 4 * s2 + g],
+                                                      acc, 0, 0, 0);
+        x[jt] = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = acc[r];
+    }
+    // this wave read only its own 16 rows of Xs (LDS accesses of one wave are served in order): overwrite them with X
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(16 * w + g + 4 * r) * PITCH + 16 * jt + li] = x[jt][r];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!wait && counter) atomicAdd(const_cast<unsigned*>(counter) + 2, 1u);   // word [2]: chains done by the safety net
+}
+
+// dacc += M M^T for the 64 x 64 slab in M (LDS, pitch 66), MFMA result layout
+__device__ __forceinline__ void coop_slab_syrk(d4_t (&dacc)[4], const double* M) {
+    constexpr int PITCH = 66;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const double av = M[(16 * w + li) * PITCH + 4 * s2 + g];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            dacc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, M[(16 * jt + li) * PITCH + 4 * s2 + g], dacc[jt], 0, 0, 0);
     }
 }
 
-// Do kernels of the second stream really run beside kernels of the main stream?  (HIP maps streams onto a few hardware
-// queues; two streams that share one are serialised, and a waiting chain would then sit in FRONT of the update it waits
-// for.)  k_chain_probe_wait is launched on the second stream, k_chain_probe_set afterwards on the main stream: out = 1
-// iff the waiter saw the flag within ~20 ms.
-__global__ void k_chain_probe_wait(const unsigned* flag, unsigned* out) {
-    unsigned seen = 0;
-    for (int spin = 0; spin < 20000 && !seen; ++spin) {
-        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(32);
+// flags: [0..7] ready (chunk b published: rows, factored diagonal block, inverse), [8..15] rows (chunk b's rows are final)
+__global__ __launch_bounds__(256, 2) void k_panel_coop(double* P, double* tail, long g0, long long* info, unsigned* flags,
+                                                        unsigned seq, unsigned* err) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    constexpr int NQ = CK_NB / 64;
+    const int b = (int)blockIdx.x;
+    const long row0 = 64 * (long)b;
+    if (b >= NQ) {      // rows below the diagonal block: follow the chain
+        for (int j = 0; j < NQ; ++j) {
+            if (!coop_wait(flags + j, seq, err)) return;      // uniform
+            if (j) __threadfence_block();                     // sub-block j reads what this workgroup stored in sub-blocks < j
+            __syncthreads();
+            lt_rows_body<true, true>(P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
+                                     tail + (long)j * 64 * 64, As, Bs);
+        }
+        return;
     }
-    *out = seen ? 1u : 0u;
+    // chunk b of the diagonal block: sub-blocks 0 .. b - 2 as above (their pivots were published long ago) ...
+    if (b == 0 && threadIdx.x == 0) __hip_atomic_store(flags + NQ, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no rows
+    for (int j = 0; j + 1 < b; ++j) {
+        if (!coop_wait(flags + j, seq, err)) return;
+        if (j) __threadfence_block();
+        __syncthreads();
+        lt_rows_body<true, true>(P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
+                                 tail + (long)j * 64 * 64, As, Bs);
+    }
+    double* D = P + row0 * CK_NB + 64 * b;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+    if (b > 0) {
+        // ... sub-block b - 1, whose pivot chunk is the previous link of the chain: everything that needs only that chunk's
+        // ROWS runs while its workgroup factors; the inverse is waited for at the last moment
+        const int j = b - 1;
+        if (!coop_wait(flags + NQ + j, seq, err)) return;
+        __threadfence_block();
+        __syncthreads();
+        d4_t cn[4];
+        coop_accumulate(cn, P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j, As, Bs);
+        // own diagonal block: the slabs of the sub-blocks already solved
+        d4_t dacc[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dacc[jt] = d4_t{0.0, 0.0, 0.0, 0.0};
+        {
+            const int sr = threadIdx.x >> 6, sc = threadIdx.x & 63;
+            const double* Ar = P + row0 * CK_NB;
+            for (int ks = 0; ks < j; ++ks) {
+                if (ks) __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 16; ++u) As[(sr + 4 * u) * 66 + sc] = Ar[(long)(sr + 4 * u) * CK_NB + 64 * ks + sc];
+                __syncthreads();
+                coop_slab_syrk(dacc, As);
+            }
+            __syncthreads();
+        }
+        if (!coop_wait(flags + j, seq, err)) return;
+        coop_finish(cn, P + row0 * CK_NB + 64 * j, CK_NB, tail + (long)j * 64 * 64, As, Bs);
+        // this chunk's rows are final: the next link may start its own accumulation
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + NQ + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        coop_slab_syrk(dacc, As);           // last slab: the rows just solved (still in LDS)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[(long)(16 * w + g + 4 * r) * CK_NB + 16 * jt + li] -= dacc[jt][r];
+        __threadfence_block();
+        __syncthreads();
+    }
+    double (*M)[66] = reinterpret_cast<double (*)[66]>(As);
+    potrf64_body(D, CK_NB, g0 + 64 * b, info, tail + (long)b * 64 * 64, M, M);
+    __threadfence();            // release (agent scope): the factored diagonal block and its inverse
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_chain_probe_set(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-void ck_launch_chain_probe(hipStream_t second, hipStream_t mainst, unsigned* flag, unsigned* out) {
-    k_chain_probe_wait<<<dim3(1), dim3(64), 0, second>>>(flag, out);
-    k_chain_probe_set<<<dim3(1), dim3(64), 0, mainst>>>(flag);
-}
-
-void ck_launch_diag_chain(hipStream_t s, double* P, double* tail, int64_t g0, long long* info, const unsigned* counter,
-                          unsigned target, unsigned* done, unsigned seq, int wait) {
-    k_diag_chain<<<dim3(1), dim3(256), 0, s>>>(P, tail, (long)g0, info, counter, target, done, seq, wait);
+void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,
+                          unsigned seq, unsigned* err) {
+    if (nrows <= 0) return;
+    k_panel_coop<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(P, tail, (long)g0, info, flags, seq, err);
 }
 
 void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail) {

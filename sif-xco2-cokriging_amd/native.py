@@ -72,6 +72,7 @@ _PROTOS = {
     "ck_debug_site_order": [c_void_p, c_int, POINTER(c_int64), c_int64],
     "ck_debug_get_entries": [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int64, _dp],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
+    "ck_debug_potrf_profile": [c_void_p, c_int, _dp],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
@@ -408,6 +409,13 @@ class Handle:
         _chk(lib().ck_debug_site_order(self._h, int(k), out.ctypes.data_as(POINTER(c_int64)), int(n_k)))
         return out
 
+    def potrf_profile(self, iters=200):
+        out = np.zeros(8)
+        _chk(lib().ck_debug_potrf_profile(self._h, int(iters), _p(out)))
+        keys = ["load_us", "factor_us", "scale_store_us", "inv_diag_us", "inv_offdiag_us", "inv_store_us", "launch_prof_us",
+                "launch_us"]
+        return dict(zip(keys, out.tolist()))
+
     def mfma_probe(self):
         out = np.empty(64 * 4 * 3, dtype=np.int32)
         _chk(lib().ck_debug_mfma_probe(self._h, out.ctypes.data_as(POINTER(c_int32))))
@@ -446,7 +454,7 @@ class Handle:
         _chk(lib().ck_timings(self._h, _p(out), 14))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
                 "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms",
-                "chain_safety_net_runs", "chain_streams_concurrent"]
+                "panel_coop_redone", "_unused"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):
