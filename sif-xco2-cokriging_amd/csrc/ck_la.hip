@@ -977,6 +977,10 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
     }
 }
 
+// (Measured and removed, round 3: the same step on EIGHT waves -- 512 threads, two accumulator tiles and eight staged
+// elements per thread, 122 VGPRs = four waves per SIMD instead of two -- bit-identical and no faster: local predictor at
+// 400 km 99.8 -> 101.2 ms, solve sweep 219.5 -> 221.1 ms.  Two workgroups fit a CU either way (LDS), and a chunk's time is
+// its chain of load -> LDS -> barrier round trips, not its MFMAs.)
 // in-group update of the diagonal block itself:  D -= A A^T,  A = S[jb .. jb + 63, g0 .. jb); both operands are the
 // same rows, so ONE 64 x 66 LDS array M serves as A and as B
 __device__ __forceinline__ void lt_diag_update(double* __restrict__ S, long ld, int g0, int i, double* M) {
