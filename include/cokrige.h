@@ -272,8 +272,11 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "exact_cov" (0/1) makes the assembly kernels evaluate K_nu per entry instead of the tables;
  * "recv_slots" (2..64, default 2; before the first assemble / ck_estimate_bytes): receive buffers for remote panels of a
  * multi-process run -- 2 for the per-panel look-ahead schedule, 2 G for the grouped one (ck_panel_apply_group);
- * "lookahead" (0/1, default 0) runs the panel step of column K+1 on a second stream under the trailing update
- * of panel K (ck_factor, ck_predict); "gemm_variant" selects this handle's GEMM tile structure (A/B tests: 7 default, 8, 5, 4, 6, 0 -- csrc/ck_la.hip);
+ * "lookahead" (-1/0/1, default -1 = automatic) runs the panel step of column K+1 on a second stream under the trailing
+ * update of the columns beyond it (per-panel updates); automatic: ck_factor uses it from 12 to 63 panels (where the update is
+ * short against the panel step and the one-launch cooperative panel step, submitted in front of the update, really runs
+ * beside it: N = 10 000: 12.8 -> 11.4 ms), grouped updates without it from 64 panels on; 1 also switches the solve sweep's
+ * variant on;
  * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
  * ck_factor / ck_predict;
  * "panel_fused" (0..31, default 18 = 2 | 16; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the

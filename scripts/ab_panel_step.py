@@ -14,7 +14,8 @@ pv = pb["params"]
 pc = pb["pcoords"][:2048]
 variants = [("launches", {"panel_fused": 2}), ("launchesG1", {"panel_fused": 2, "panel_group": 1}),
             ("coop", {"panel_fused": 2 | 16}), ("coopG1", {"panel_fused": 2 | 16, "panel_group": 1}),
-            ("coopG2", {"panel_fused": 2 | 16, "panel_group": 2}), ("coopG4", {"panel_fused": 2 | 16, "panel_group": 4})]
+            ("coopG2", {"panel_fused": 2 | 16, "panel_group": 2}), ("coopG4", {"panel_fused": 2 | 16, "panel_group": 4}),
+            ("coopLA", {"panel_fused": 2 | 16, "lookahead": 1}), ("launchesLA", {"panel_fused": 2, "lookahead": 1})]
 if which:
     variants = [v for v in variants if v[0] in which]
 hs = []

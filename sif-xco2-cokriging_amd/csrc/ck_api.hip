@@ -183,7 +183,14 @@ struct ck_handle {
     double* d_chunkb = nullptr;       // chunk bounds of the sites for the radius search (ck_local.hip: LpSearch)
     double* local_slab = nullptr;     // scratch of ck_predict_local, kept between calls (allocating tens of GiB
     long long local_slab_doubles = 0; // costs up to seconds, erratically); grows when a call needs more
-    bool lookahead = false;   // measured: no gain -- the side queue starves behind the big update kernel
+    // option "lookahead": the panel step of column K + 1 on a second stream under the trailing update of the columns beyond
+    // it (per-panel updates, no grouping).  With 24 launches per panel step it gained nothing (the side queue's launches
+    // starve behind the resident update kernel); with the ONE-launch cooperative panel step, submitted in front of
+    // the update, it does where the update is short against the panel step: factor_ms at N = 10 000: 12.8 -> 11.4,
+    // N = 18 000: 44.9 -> 41.6, N = 28 000: 130.7 -> 127.9, N = 40 000: 351.5 (groups of 3) against 356.8.
+    // -1 = automatic: on for the factorisation from 12 to 63 panels when the panel step is cooperative and no panel_group is
+    // forced; 0 / 1 = off / on (1 also switches the solve sweep's variant on)
+    int lookahead = -1;
     // the cooperative panel step (ck_la.hip: k_panel_coop, option "panel_fused" bit 4): [0..15] its flags, [16] its error word
     unsigned* d_coop = nullptr;
     unsigned coop_seq = 0;
@@ -977,10 +984,15 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
 
 static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 3 : 1); }
 
+static bool factor_lookahead(const ck_handle* h) {
+    if (h->lookahead >= 0) return h->lookahead != 0;
+    return (h->panel_fused & 16) && h->panel_group == 0 && h->world == 1 && h->nK >= 12 && h->nK < 64;
+}
+
 static int factor_sweep(ck_handle* h) {
     h->gemm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (h->lookahead) {
+    if (factor_lookahead(h)) {
         // Look-ahead: as soon as panel K has updated block column K + 1, the panel step of K + 1
         // starts on the side stream and runs under the update of the columns K + 2.. by panel K.
         if (ensure_events(h)) return -1;
@@ -1032,7 +1044,7 @@ static int factor_sweep(ck_handle* h) {
 
 // forward sweep of the right-hand-side rows through the factor (the L panels are final)
 static int solve_sweep(ck_handle* h) {
-    if (h->lookahead) {
+    if (h->lookahead > 0) {
         if (ensure_events(h)) return -1;
         hipStream_t M = h->stream, S = h->side;
         aux_inner_on(h, 0, h->sig[0], M);
@@ -1294,7 +1306,8 @@ struct SchurSwap {
     int nK, time_gemm, world, rank;
     int64_t Npad, nend;
     long long* d_info;
-    bool lookahead, assembled;
+    int lookahead;
+    bool assembled;
     explicit SchurSwap(ck_handle* hh, int nJ, int64_t Mp, int64_t m_valid) : h(hh) {
         sig = h->sig;
         d_sigptr = h->d_sigptr;
@@ -1315,7 +1328,7 @@ struct SchurSwap {
         h->nend = m_valid;
         h->d_info = h->d_sch_info;
         h->time_gemm = 0;
-        h->lookahead = false;
+        h->lookahead = 0;
         h->assembled = true;
         h->world = 1;
         h->rank = 0;
@@ -2097,7 +2110,7 @@ extern "C" int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8) {
         for (int j = 0; j <= i; ++j) A[(size_t)i * 512 + j] = (i == j ? 70.0 : 0.0) + 1.0 / (1.0 + i + j);
     HIPCHK(hipMemsetAsync(dinfo, 0, 8, h->stream));
     HIPCHK(hipMemsetAsync(dprof, 0, 16 * 8, h->stream));
-    double clk_mhz = 100.0;   // s_memtime counts the 100 MHz reference clock on gfx9
+    double clk_mhz = 100.0;   // provisional unit; rescaled below so that the phases add up to the instrumented launch
     long long hp[16];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int it = 0; it < 4; ++it) {
@@ -2123,6 +2136,12 @@ extern "C" int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         out8[6 + which] = (double)ms * 1e3 / iters;
+    }
+    {   // s_memtime ticks at the shader clock: scale the phases so that they add up to the instrumented launch's duration
+        double sum = 0;
+        for (int k = 0; k < 6; ++k) sum += out8[k];
+        if (sum > 0)
+            for (int k = 0; k < 6; ++k) out8[k] *= out8[6] / sum;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2213,8 +2232,9 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->time_gemm = (int)value;
         return 0;
     }
-    if (!strcmp(name, "lookahead")) {   // 0: strictly sequential panel / update steps on one stream
-        h->lookahead = value != 0;
+    if (!strcmp(name, "lookahead")) {   // see ck_handle::lookahead
+        if (value < -1 || value > 1) return fail("lookahead must be -1 (automatic), 0 or 1");
+        h->lookahead = (int)value;
         return 0;
     }
     if (!strcmp(name, "local_slab_mb")) {

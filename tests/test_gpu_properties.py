@@ -68,15 +68,18 @@ def test_panel_groups(group):
         h.close()
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2, 3])
-def test_panel_fused_variants(fused):
+@pytest.mark.parametrize("fused,lookahead", [(0, 0), (1, 0), (2, 0), (3, 0), (2 | 4, 0), (2 | 16, 0), (16, 0), (2 | 16, 1), (2, 1),
+                                             (2 | 16, -1)])
+def test_panel_fused_variants(fused, lookahead):
     """option panel_fused: the 64-column sub-blocks inside a panel right-looking with three launches each (0) or
     left-looking with the update fused into the factor / row-solve launch, for the factorisation (bit 0) and the
-    right-hand-side rows (bit 1) -- predictions, LOOCV and a not-positive-definite index against the oracle."""
+    right-hand-side rows (bit 1); the diagonal block first (bit 2); the whole panel step in one launch of cooperating
+    workgroups (bit 4, the default); with and without the panel step on a second stream under the trailing update
+    (option lookahead) -- predictions and LOOCV against the oracle."""
     from sif_xco2_cokriging_amd import synth
     pb = synth.conus_problem(1500, seed=12)
     pc = pb["pcoords"][::13][:500]
-    h = _handle(pb, options={"panel_fused": fused})
+    h = _handle(pb, options={"panel_fused": fused, "lookahead": lookahead})
     try:
         p = orc.Params.from_flat(pb["params"])
         pred, err = h.predict(0, pc)
@@ -141,3 +144,41 @@ def test_config3_properties_n20000():
     # at data sites the conditional variance given ALL data is below the leave-one-out variance
     pa, ea = h.predict(0, pb["coords"][0][:200])
     assert np.all(ea ** 2 <= le[:200] ** 2 + 1e-9)
+
+
+def test_defaults_across_the_schedule_boundaries_agree_with_the_plain_schedule():
+    """The factorisation picks its schedule by size -- per-panel updates below 12 panels, the panel step on a second
+    stream under the update from 12 to 63, groups of three panels from 64 on (40 without the cooperative panel step) --:
+    at 14 panels (N = 7 000: the automatic look-ahead) the default agrees with the strictly sequential, one-launch-per-
+    dependency schedule to rounding, for both processes, and reports a not-positive-definite Sigma at the same index."""
+    from sif_xco2_cokriging_amd import native, synth
+    pb = synth.conus_problem(3500, seed=13)
+    pc = pb["pcoords"][::9][:800]
+    h1 = _handle(pb)                                                    # defaults
+    h2 = _handle(pb, options={"panel_fused": 0, "lookahead": 0, "panel_group": 1})
+    try:
+        assert h1.num_panels()[0] == 14
+        for i in (0, 1):
+            a, b = h1.predict(i, pc), h2.predict(i, pc)
+            assert rel(a[0], b[0]) < 1e-11 and rel(a[1], b[1]) < 1e-11
+        assert h1.timings()["panel_coop_redone"] == 0
+    finally:
+        h1.close()
+        h2.close()
+    # not positive definite (rho_12 beyond the admissible range of the bivariate Matern): same minor from both schedules
+    pv = list(pb["params"])
+    pv[10] = -0.999
+    pv[3] = 3.4          # nu_12 far above (nu_11 + nu_22) / 2
+    infos = []
+    for opts in ({}, {"panel_fused": 0, "lookahead": 0, "panel_group": 1}):
+        h = native.Handle(0)
+        for k, v in opts.items():
+            h.set_option(k, v)
+        h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+        h.set_metric(pb["metric"])
+        for k in range(2):
+            h.set_data(k, pb["coords"][k], pb["values"][k])
+        h.assemble_joint()
+        infos.append(h.factor())
+        h.close()
+    assert infos[0] == infos[1] and infos[0] > 0, infos
