@@ -15,7 +15,8 @@ pc = pb["pcoords"][:2048]
 variants = [("launches", {"panel_fused": 2}), ("launchesG1", {"panel_fused": 2, "panel_group": 1}),
             ("coop", {"panel_fused": 2 | 16}), ("coopG1", {"panel_fused": 2 | 16, "panel_group": 1}),
             ("coopG2", {"panel_fused": 2 | 16, "panel_group": 2}), ("coopG4", {"panel_fused": 2 | 16, "panel_group": 4}),
-            ("coopLA", {"panel_fused": 2 | 16, "lookahead": 1}), ("launchesLA", {"panel_fused": 2, "lookahead": 1})]
+            ("coopLA", {"panel_fused": 2 | 16, "lookahead": 1}), ("launchesLA", {"panel_fused": 2, "lookahead": 1}),
+            ("default", {}), ("LA0", {"lookahead": 0})]
 if which:
     variants = [v for v in variants if v[0] in which]
 hs = []
@@ -41,7 +42,13 @@ for it in range(reps + 1):
 ref = None
 for (name, _), h in zip(variants, hs):
     t = h.timings()
-    pred, err = h.predict(0, pc)
+    pcs = pb["pcoords"] if os.environ.get("CK_AB_FULL_GRID") else pc
+    sv = []
+    for _ in range(3):
+        pred, err = h.predict(0, pcs)
+        sv.append(h.timings()["solve_ms"])
+    pred, err = pred[:len(pc)] if len(pcs) != len(pc) else pred, err[:len(pc)] if len(pcs) != len(pc) else err
+    print(f"   solve_ms ({len(pcs)} points) {' '.join(f'{x:.2f}' for x in sv)}")
     if ref is None:
         ref = (pred, err)
     dp = np.max(np.abs(pred - ref[0])) / np.max(np.abs(ref[0]))

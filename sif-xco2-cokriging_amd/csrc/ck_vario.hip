@@ -434,7 +434,7 @@ struct VarioPairCtx {
 // distances (dthr < 0, ck_api.hip: ck_vario_bin): deferred to the host -- listed, if `list_it` (level e0 of a
 // follow-up window was listed as the previous window's last level) -- and here "not above".
 template <int METRIC>
-__device__ __forceinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c, int lev, bool list_it) {
+__device__ __noinline__ bool vario_near(vg_args_ptr a, const VarioPairCtx& c, int lev, bool list_it) {
     if (METRIC == CK_METRIC_EUCLID) {
         const double thr = vg_const(a->dthr)[lev];
         if (thr >= 0.0) return euclid_exact(c.ax, c.ay, c.bx, c.by) > thr;
