@@ -11,7 +11,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -37,6 +37,9 @@ cp(f"{G}/prof_{tag}_vario_pmc.txt", f"{tag}_variogram_1M_pmc.txt")
 cp(f"{G}/prof_{tag}_local.json", f"{tag}_local_predictor.json")
 cp(f"{G}/prof_{tag}_local_pmc.txt", f"{tag}_local_400km_pmc.txt")
 cp(f"{G}/prof_{tag}_loocv.json", f"{tag}_loocv.json")
+cp(f"{G}/prof_{tag}_assembly.txt", f"{tag}_assembly_k1_k2.txt")
+cp(f"{G}/prof_{tag}_panel_step.txt", f"{tag}_panel_step.txt")
+cp(f"{G}/prof_{tag}_bench_2rank_gloo.json", f"{tag}_bench_2rank_gloo_one_gpu.json")
 for name, out in ((f"prof_vario_{tag}", f"{tag}_variogram_1M_kernel_stats.csv"), (f"prof_local_{tag}", f"{tag}_local_400km_kernel_stats.csv")):
     f = glob.glob(f"{G}/{name}/**/*kernel_stats.csv", recursive=True)
     if f:
@@ -55,7 +58,7 @@ if os.path.exists(fe) and os.path.exists(wr):
     nK = -(-N // NB)
     Np = nK * NB
     launches = []
-    for K0 in range(0, nK, 3):
+    for K0 in range(0, nK, 3):   # (79 panels: groups of three, no look-ahead -- the automatic schedule from 64 panels on)
         Gc = min(3, nK - K0)
         for g in range(1, Gc):
             rows = Np - (K0 + g) * NB

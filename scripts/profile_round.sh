@@ -4,7 +4,7 @@
 #   2. variogram (1 M soundings): kernel stats + SQ counters of the pair kernels
 #   3. local predictor (400 km): kernel stats + SQ counters of its matrix-core kernels
 # Outputs under gpurun_out/prof_<tag>*/ ; copy the summaries into profiles/ (scripts/collect_profiles.py).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 scripts/profile_bench.sh $TAG > gpurun_out/prof_${TAG}_bench.txt 2>&1
@@ -22,4 +22,14 @@ python3 scripts/bench_variogram.py 1000000 > gpurun_out/prof_${TAG}_vario_1M.jso
 python3 scripts/bench_variogram.py 1000000 cross cpu >> gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
 python3 scripts/bench_local.py 20000 50 100 200 400 600 > gpurun_out/prof_${TAG}_local.json 2>/dev/null
 python3 scripts/bench_loocv.py > gpurun_out/prof_${TAG}_loocv.json 2>/dev/null
+python3 scripts/bench_variogram.py 1000000 euclid >> gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
 echo "bench lines done"
+# round 3: assembly kernels K1 / K2 (timings + SQ counters), the panel step's variants, the potrf phase profile, and the
+# two-rank rehearsal of the multi-GPU form on this one GPU (gloo; calibration and schedule tuning included)
+python3 scripts/time_assembly.py > gpurun_out/prof_${TAG}_assembly.txt 2>/dev/null
+scripts/pmc_kernel.sh ${TAG}_asm "k_assemble" scripts/time_assembly.py >> gpurun_out/prof_${TAG}_assembly.txt 2>&1
+python3 scripts/ab_panel_step.py 20000 3 launches,coop,coopLA 2>/dev/null | grep "^N=" > gpurun_out/prof_${TAG}_panel_step.txt
+python3 scripts/ab_panel_step.py 5000 3 launches,coop,coopLA 2>/dev/null | grep "^N=" >> gpurun_out/prof_${TAG}_panel_step.txt
+python3 scripts/diag_potrf.py 2>/dev/null >> gpurun_out/prof_${TAG}_panel_step.txt
+CK_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench_2rank_gloo.json 2>/dev/null
+echo "round-3 extras done"
