@@ -54,6 +54,11 @@ int ck_device_count(int* n);
 
 /* ---- handle ---------------------------------------------------------------- */
 int ck_create(int device_id, ck_handle** out);
+/* The multi-GPU form of ck_create (SURVEY.md section 8b lists ck_create(device_ids, n_dev, ...)): the run is one process
+ * -- one handle -- per GPU; every rank passes the SAME device list and its own rank and gets a handle on device_ids[rank]
+ * that is already partitioned (ck_set_partition(rank, n_dev)).  The panels then travel between the ranks' ck_panel_buffer
+ * addresses by whatever the host framework provides (RCCL under torch.distributed in distributed.py / workers.py). */
+int ck_create_partitioned(const int* device_ids, int n_dev, int rank, ck_handle** out);
 int ck_destroy(ck_handle* h);
 /* external != 0: launch on the caller's HIP stream (hipStream_t, e.g.
  * torch.cuda.current_stream().cuda_stream; NULL is the legacy default stream, which is what

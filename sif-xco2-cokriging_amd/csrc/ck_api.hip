@@ -258,6 +258,14 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
     return 0;
 }
 
+extern "C" int ck_create_partitioned(const int* device_ids, int n_dev, int rank, ck_handle** out) {
+    if (!device_ids || n_dev < 1 || rank < 0 || rank >= n_dev) return fail("bad device list / rank");
+    if (ck_create(device_ids[rank], out)) return -1;
+    (*out)->rank = rank;
+    (*out)->world = n_dev;
+    return 0;
+}
+
 static void vario_free(ck_handle* h);
 static void schur_free(ck_handle* h);
 

@@ -29,6 +29,7 @@ _PROTOS = {
     "ck_version": [],
     "ck_device_count": [POINTER(c_int)],
     "ck_create": [c_int, POINTER(c_void_p)],
+    "ck_create_partitioned": [POINTER(c_int), c_int, c_int, POINTER(c_void_p)],
     "ck_destroy": [c_void_p],
     "ck_set_stream": [c_void_p, c_void_p, c_int],
     "ck_set_arena": [c_void_p, c_void_p, c_int64],
@@ -179,10 +180,16 @@ def device_count() -> int:
 class Handle:
     """One GPU, one HIP stream, one cokriging problem (see include/cokrige.h)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None, rank: int = 0):
+        """device: one GPU, one problem.  devices + rank: this process's handle of a multi-GPU run (one process per
+        entry of `devices`), already partitioned (rank, len(devices)) -- include/cokrige.h: ck_create_partitioned."""
         self._h = c_void_p()
         self._keep = []
-        _chk(lib().ck_create(int(device), byref(self._h)))
+        if devices is None:
+            _chk(lib().ck_create(int(device), byref(self._h)))
+        else:
+            ids = (c_int * len(devices))(*[int(d) for d in devices])
+            _chk(lib().ck_create_partitioned(ids, len(devices), int(rank), byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -65,7 +65,7 @@ def _rank_main(rank, world, device, port, backend, conn, opts):
 
         def new_handle():
             ld = state["loaded"]
-            h = native.Handle(device)
+            h = native.Handle(devices=opts["devices"], rank=rank)      # ck_create_partitioned: device = devices[rank]
             h.set_model(*ld["model"])
             h.set_metric(ld["metric"])
             for k, (c, v) in enumerate(zip(ld["coords"], ld["values"])):
@@ -153,7 +153,7 @@ class RankPool:
         ctx = mp.get_context("spawn")
         port = _free_port()
         self._conns, self._procs = [], []
-        opts = {"exchange": exchange, "panel_group": panel_group}
+        opts = {"exchange": exchange, "panel_group": panel_group, "devices": list(self.devices)}
         for r, d in enumerate(self.devices):
             a, b = ctx.Pipe()
             p = ctx.Process(target=_rank_main, args=(r, self.world, d, port, self.backend, b, opts), daemon=True)
