@@ -237,8 +237,14 @@ def main():
                                               panel_group=pg if pg == "auto" else int(pg))
         runner.prepare(m_total=m)
         h.set_option("time_gemm", 2)   # HIP events around this rank's Sigma trailing-update launches
-        runner.calibrate()
-        runner.autotune(0, pb["pcoords"])   # untimed calibration passes, in front of the W warm-up steps
+        cand = os.environ.get("CK_PANEL_EXCHANGE_CANDIDATES")
+        tuning_error = None
+        try:
+            runner.calibrate(candidates=cand.split(",") if cand else None)
+            runner.autotune(0, pb["pcoords"])   # untimed calibration passes, in front of the W warm-up steps
+        except Exception as e:   # noqa: BLE001 -- a tuning step must never cost the run its number: plain defaults instead
+            tuning_error = f"{type(e).__name__}: {e}"
+            runner.exchange, runner.G = "broadcast", 1
 
         def step():
             return runner.predict(0, pb["pcoords"])
@@ -303,7 +309,7 @@ def main():
                      "p2p": "panel scatter + point-to-point all-gather (batch_isend_irecv)"}
             out["comm"] = {"collective": names.get(runner.exchange, runner.exchange) + f" over {backend}, one per 512-column panel, look-ahead kept",
                            "exchange": runner.exchange, "exchange_calibration": runner.comm_info,
-                           "panel_group": runner.G, "panel_group_tuning": runner.tune_info,
+                           "panel_group": runner.G, "panel_group_tuning": runner.tune_info, "tuning_error": tuning_error,
                            "panels": nK, "bytes_received_per_rank_per_step": int(sum((nK * 512 - K * 512) * 512 * 8 + 8 * 64 * 64 * 8
                                                                                      for K in range(nK) if K % world != 0)),
                            "note": "bcast_wait_ms = time the rank's stream waited for a panel after its own updates were done "

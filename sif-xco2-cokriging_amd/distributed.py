@@ -284,21 +284,26 @@ class DistributedJoint:
             import torch
             torch.cuda.synchronize(self.device)
 
-    def calibrate(self, reps: int = 2):
-        """exchange = "auto": send one mid-size panel through every exchange this backend offers (one warm-up, `reps`
+    def calibrate(self, reps: int = 2, candidates=None):
+        """exchange = "auto": send one mid-size panel through every candidate exchange (one warm-up, `reps`
         timed repetitions, host clock around device synchronisation), MAX over the ranks of each, and keep the
         fastest -- every rank computes the same choice from the same reduced numbers.  The panel's content is
-        whatever the buffers hold (call before or between passes, not inside one)."""
+        whatever the buffers hold (call before or between passes, not inside one).
+        candidates: default ("broadcast", "sag") -- two forms built from standard collectives only; "p2p" (hand-rolled
+        batch_isend_irecv phases) competes when asked for (CK_PANEL_EXCHANGE_CANDIDATES=broadcast,sag,p2p for bench.py):
+        it has run on gloo and through a host-staged facade, never on RCCL, and the first multi-GPU run should not
+        depend on it."""
         import time
         if self.world == 1 or self.exchange != "auto":
             return self.comm_info
         nK = self.h.num_panels()[0]
         K = nK // 2
         src = K % self.world
+        want = tuple(candidates) if candidates else ("broadcast", "sag")
         cands = ["broadcast"]
-        if hasattr(self.dist, "all_gather_into_tensor"):
+        if "sag" in want and hasattr(self.dist, "all_gather_into_tensor"):
             cands.append("sag")
-        if self.world >= 3 and hasattr(self.dist, "P2POp"):
+        if "p2p" in want and self.world >= 3 and hasattr(self.dist, "P2POp"):
             cands.append("p2p")
         ms = []
         for how in cands:

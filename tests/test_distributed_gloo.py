@@ -40,7 +40,7 @@ def _worker(rank, world, port, case, q):
             r = DistributedJoint(h, rank, world, dist_module=dist, lookahead="sequential" not in tok,
                                  exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
             if exchange == "auto":
-                info = r.calibrate(reps=1)
+                info = r.calibrate(reps=1, candidates=("broadcast", "sag", "p2p"))
                 assert info["exchange"] in ("broadcast", "sag", "p2p") and r.exchange == info["exchange"]
                 assert all(info["calibration_ms"][k] is not None for k in ("broadcast", "sag", "p2p")), info   # all ran
             if group == "auto":

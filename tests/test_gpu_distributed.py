@@ -104,7 +104,7 @@ def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast", gro
         dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
         r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
         if exchange == "auto":
-            info = r.calibrate(reps=1)
+            info = r.calibrate(reps=1, candidates=("broadcast", "sag", "p2p"))
             assert r.exchange in ("broadcast", "sag", "p2p") and info["calibration_ms"]["broadcast"] is not None, info
         pred, err = r.autotune(0, g["pcoords_A"]) if group == "auto" else r.predict(0, g["pcoords_A"])
         assert r.timings["update_ms"] > 0 and r.timings["bcast_wait_ms"] >= 0
