@@ -440,17 +440,23 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     // (Tried: the chunk's barrier in the middle of its MFMAs with a second fragment set, so that every
     // LDS read is issued 16 MFMAs before its use -- correct, 3 % slower than this plain order; s_setprio 1 around
     // the chunk's MFMAs -- 1 % slower.)
+    // The DMA of chunk st + 2 is issued right BEHIND the barrier of chunk st -- into the stage chunk st has just been read
+    // from -- and waited for in front of the barrier of chunk st + 1.  hipcc sinks the second half of a chunk's MFMAs below
+    // its barrier, so with the DMA issued at the TOP of the next iteration (rounds 1-2) a transfer had only the first
+    // half-chunk's 16 MFMAs to land; issued here it has a whole chunk (32 MFMAs) and still needs no third LDS stage.
     const int nst = np * NST;
     int pnl = 0, kc = 0;             // panel and chunk-in-panel of the chunk being PREFETCHED
+#define CK_DMA_NEXT(stage_)                                   \
+    {                                                         \
+        if (++kc == NST) {                                    \
+            kc = 0;                                           \
+            src.get(++pnl, Ab, Bb);                           \
+        }                                                     \
+        CK_DMA_CHUNK((stage_), (long)kc * (GEMM_BK * 8));     \
+    }
+    if (nst > 1) CK_DMA_NEXT(1);     // chunk 1 (chunk 0 has landed: waited for above)
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
-        if (st + 1 < nst) {
-            if (++kc == NST) {
-                kc = 0;
-                src.get(++pnl, Ab, Bb);
-            }
-            CK_DMA_CHUNK(cur ^ 1, (long)kc * (GEMM_BK * 8));
-        }
         const char* sb = lds + cur * STAGE;
         d2_t af[2][4], bf[2][WJ];
 #pragma unroll
@@ -460,18 +466,29 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 #pragma unroll
             for (int j = 0; j < WJ; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
         }
+        // first half-chunk's MFMAs, then the barrier, then -- fenced, so that the scheduler cannot put the second
+        // half-chunk's MFMAs in front of it -- the DMA of chunk st + 2, then the second half-chunk
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < WJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb][i][h], bf[kb][j][h], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i][h], bf[0][j][h], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next chunk is in LDS
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < nst) CK_DMA_NEXT(cur);   // every wave has finished reading this stage
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < WJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i][h], bf[1][j][h], acc[i][j], 0, 0, 0);
     }
+#undef CK_DMA_NEXT
 #undef CK_DMA_CHUNK
 #pragma unroll
     for (int i = 0; i < 4; ++i)
