@@ -1695,11 +1695,14 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             int na = nb;
             const int G = h->local_group;
             for (int g0 = 0; g0 < kq_max; g0 += 64 * G) {
+                // the group's diagonal region block by block (diagonal block, then the few chunks of rows inside the region) ...
                 for (int b = 0; b < G && g0 + 64 * b < kq_max; ++b) {
                     while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * b) --na;   // finished systems drop off the end
-                    ck_launch_local_tiled_block(h->stream, bsys, d_slab, na, g0, b, kq_max, d_linfo + tb.first);
+                    ck_launch_local_tiled_block(h->stream, bsys, d_slab, na, g0, b, kq_max, d_linfo + tb.first, G);
                 }
+                // ... then every row below it through all of the group's blocks in one launch, then the trailing update
                 while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * G) --na;
+                ck_launch_local_tiled_rows_all(h->stream, bsys, d_slab, na, g0, G, kq_max);
                 ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kq_max);
             }
             ck_launch_local_reduce_t(h->stream, bsys, nb, d_slab, d_linfo + tb.first, c0var, d_out, d_out + mp);
@@ -2256,7 +2259,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "local_group")) {
-        if (value < 1 || value > 16) return fail("local_group must be in [1, 16]");
+        if (value < 1 || value > CK_LT_NINV) return fail("local_group must be in [1, 8]");
         h->local_group = (int)value;
         return 0;
     }

@@ -186,7 +186,7 @@ int ck_local_lds_limit();
 //         their forward substitution (L[r][j] = (S[r][j] - sum) / L[j][j]) and never see a bad pivot there.
 //         The 128 rows / columns beyond kq exist only so that whole tiles can be read and written without
 //         bounds checks; nothing valid depends on them.
-//   Linv  64 x 64 doubles (inverse of the current diagonal block)
+//   Linv  CK_LT_NINV x 64 x 64 doubles (inverses of the diagonal blocks of the current column group)
 //   idx   k ints (neighbour list)
 struct CkLocalSys {
     long long off;      // doubles into the slab
@@ -194,10 +194,11 @@ struct CkLocalSys {
 };
 #define CK_LT_BIG 1e200
 #define CK_LT_ROWS(kq) ((kq) + 128)
+#define CK_LT_NINV 8   // inverses of the diagonal blocks of one column group kept side by side (option local_group <= 8)
 static inline long long ck_local_tiled_kq(long long k) { return (k + 2 + 63) / 64 * 64; }
 static inline long long ck_local_tiled_doubles(long long k) {
     const long long kq = ck_local_tiled_kq(k);
-    return (CK_LT_ROWS(kq) * (kq + 128) + 64 * 64 + (k + 1) / 2 + 1) & ~1LL;
+    return (CK_LT_ROWS(kq) * (kq + 128) + CK_LT_NINV * 64 * 64 + (k + 1) / 2 + 1) & ~1LL;
 }
 void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, int i_pred, int cv, double max_dist,
                                 const double* pc, int64_t mpad, const double* sc, const double* z, CkLayout L,
@@ -210,7 +211,10 @@ void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, 
 // read-modify-write traffic of updating after every block).  Systems sorted by k descending: the first n_active
 // are the ones that still have the block / trailing columns in question.
 void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
-                                 int kq_max, long long* info);
+                                 int kq_max, long long* info, int group_blocks);
+// the rows BELOW the group's diagonal region, through all of the group's blocks in one launch (group_blocks of them)
+void ck_launch_local_tiled_rows_all(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0,
+                                    int group_blocks, int kq_max);
 void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
                                     int kq_max);
 void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,

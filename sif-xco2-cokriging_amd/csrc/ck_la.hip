@@ -651,7 +651,10 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
         if (threadIdx.x == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime();    \
     }
 // PROF (diagnostic build of the kernel only: ck_debug_potrf_profile): shader-clock stamps at the phase boundaries
-template <bool PROF = false>
+// COLS4: four columns per barrier (the latency-bound uses: one diagonal block at a time in the joint path's panel chain)
+// or one (the local predictor's batched diagonal blocks, thousands of workgroups per launch: THROUGHPUT counts there, and
+// the four-column form's redundant in-register elimination makes every workgroup do more: 10.8 -> 12.5 ms per 400 km run)
+template <bool PROF = false, bool COLS4 = true>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, long g0, long long* info,
                                              double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66],
                                              long long* prof = nullptr) {
@@ -676,6 +679,45 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
         if (sum == 1.2345e300) prof[15] = 1;   // the loads have landed
     }
     CK_POTRF_MARK(1)
+    if (!COLS4) {
+        // one column per barrier: at step j the owners of column j publish it through a double-buffered LDS vector, then
+        // every thread updates a[i][k] -= a[i][j] a[k][j] / a[j][j] for its elements with j < k <= i
+        double* const colbuf[2] = {&pan[0][0][0], &pan[1][0][0]};
+        for (int jb = 0; jb < 16; ++jb) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jb + jj;
+                double* cb = colbuf[jj & 1];
+                if (bk == jb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cb[4 * bi + r] = a[r][jj];
+                }
+                __syncthreads();
+                const double piv = cb[j];
+                if (t == 0) {
+                    pv[j] = piv;
+                    if (!(piv > 0.0)) atomicCAS((unsigned long long*)info, 0ULL, (unsigned long long)(g0 + j + 1));
+                }
+                if (lower && bk >= jb) {
+                    double rp = __builtin_amdgcn_rcp(piv);
+                    rp = fma(fma(-piv, rp, 1.0), rp, rp);
+                    rp = fma(fma(-piv, rp, 1.0), rp, rp);
+                    double li[4], lk[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) li[r] = cb[4 * bi + r] * rp;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lk[c] = cb[4 * bk + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const bool upd = (bk > jb || c > jj) && (4 * bk + c <= 4 * bi + r);
+                            if (upd) a[r][c] -= li[r] * lk[c];
+                        }
+                }
+            }
+        }
+    }
     // Four columns per barrier: the owners of block column jb publish their 4 x 4 blocks (a 64 x 4 panel); every thread
     // that still has work eliminates the panel's four columns ON ITS OWN COPIES of the three pieces it needs -- the
     // 4 x 4 diagonal block D, the rows of its block row (Pi) and of its block column (Pk) -- and applies the four rank-1
@@ -683,7 +725,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
     // LDS round trips and barriers it replaces: 64 dependent steps become 16 (23 -> 12 us for the factorisation).
     // As before the columns stay UNSCALED (a[i][k] -= a[i][j] a[k][j] / a[j][j]); L[i][j] = a[i][j] / sqrt(a[j][j]) once
     // at the end.  Entries above the diagonal inside diagonal blocks carry garbage and are never used.
-    for (int jb = 0; jb < 16; ++jb) {
+    for (int jb = 0; COLS4 && jb < 16; ++jb) {
         double (*pb)[68] = pan[jb & 1];
         if (bk == jb && bi >= jb) {
 #pragma unroll
@@ -1044,23 +1086,54 @@ __global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict
         lt_diag_update(S, q.ld, g0, i, &M[0][0]);
         __syncthreads();   // the block is re-read from memory by other threads of this workgroup
     }
-    potrf64_body(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x,
-                 jb + 64 < q.kq ? S + (long)CK_LT_ROWS(q.kq) * q.ld : nullptr, M, M);
+    potrf64_body<false, false>(S + (long)jb * q.ld + jb, q.ld, jb, info + blockIdx.x,
+                               jb + 64 < q.kq ? S + (long)CK_LT_ROWS(q.kq) * q.ld + (long)i * 64 * 64 : nullptr, M, M);   // inverse slot i
 }
 
-// rows below the diagonal block: in-group update and row solve
+// Rows below the diagonal block of block i, INSIDE the group's diagonal region (rows < g0 + 64 gb): in-group update and
+// row solve, step by step with the diagonal blocks (k_lt_potrf64) -- these few chunks are what the next diagonal block
+// waits for.  The rows below the region go through all of the group's blocks at once afterwards (k_lt_rows_all).
 __global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
-                                                     int i) {
+                                                     int i, int gb) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
     const CkLocalSys q = sys[blockIdx.y];
     const int jb = g0 + 64 * i;
-    const int nchunk = (q.kq - jb - 64) / 64;   // rows jb + 64 .. kq - 1
+    const int lim = q.kq < g0 + 64 * gb ? q.kq : g0 + 64 * gb;
+    const int nchunk = (lim - jb - 64) / 64;   // rows jb + 64 .. lim - 1
     if ((int)blockIdx.x >= nchunk) return;
     double* S = slab + q.off;
     const long row0 = jb + 64 + 64 * (long)blockIdx.x;
     lt_rows_body<true>(S + row0 * q.ld + jb, S + row0 * q.ld + g0, q.ld, S + (long)jb * q.ld + g0, q.ld, i,
-                       S + (long)CK_LT_ROWS(q.kq) * q.ld, As, Bs);
+                       S + (long)CK_LT_ROWS(q.kq) * q.ld + (long)i * 64 * 64, As, Bs);
+}
+
+// The rows below the group's diagonal region (row >= g0 + 64 gb): one workgroup walks a 64-row chunk through ALL of the
+// group's blocks -- block i: update by the chunk's own columns of the blocks before it (still in cache: this workgroup
+// wrote them), solve against diagonal block i with its inverse (slot i).  Against one launch per block over all rows
+// (rounds 1-2) every chunk's columns of the group are read from memory once and written once instead of being re-read
+// by every later block of the group (64 i columns at block i: 448 KB -> 256 KB per chunk and group of four), and the
+// launches of a group drop from 2 gb to gb + (gb - 1) + 1, the big ones from gb to one.
+__global__ __launch_bounds__(256, 2) void k_lt_rows_all(const CkLocalSys* __restrict__ sys, double* __restrict__ slab,
+                                                         int g0, int gb) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    const CkLocalSys q = sys[blockIdx.y];
+    const int r_first = g0 + 64 * gb;
+    const int nchunk = (q.kq - r_first) / 64;
+    if ((int)blockIdx.x >= nchunk) return;
+    double* S = slab + q.off;
+    const long row0 = r_first + 64 * (long)blockIdx.x;
+    const double* linv = S + (long)CK_LT_ROWS(q.kq) * q.ld;
+    for (int i = 0; i < gb; ++i) {
+        if (i) {   // block i reads what other threads of this workgroup stored in the blocks before it
+            __threadfence_block();
+            __syncthreads();
+        }
+        const int jb = g0 + 64 * i;
+        lt_rows_body<true>(S + row0 * q.ld + jb, S + row0 * q.ld + g0, q.ld, S + (long)jb * q.ld + g0, q.ld, i,
+                           linv + (long)i * 64 * 64, As, Bs);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1356,11 +1429,19 @@ __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restri
 
 // block i of the group at g0 for the first n_active systems (those with kq > g0 + 64 i)
 void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
-                                 int kq_max, long long* info) {
+                                 int kq_max, long long* info, int group_blocks) {
     if (n_active <= 0) return;
     k_lt_potrf64<<<dim3((unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, info);
-    const int rows = kq_max - (g0 + 64 * i) - 64;
-    if (rows > 0) k_lt_rows<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i);
+    const int lim = kq_max < g0 + 64 * group_blocks ? kq_max : g0 + 64 * group_blocks;
+    const int rows = lim - (g0 + 64 * i) - 64;   // inside the group's diagonal region only
+    if (rows > 0) k_lt_rows<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, group_blocks);
+}
+
+void ck_launch_local_tiled_rows_all(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0,
+                                    int group_blocks, int kq_max) {
+    const int rows = kq_max - g0 - 64 * group_blocks;
+    if (n_active <= 0 || rows <= 0) return;
+    k_lt_rows_all<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, group_blocks);
 }
 
 // trailing update behind the group [g0, g0 + K) for the first n_active systems (those with kq > g0 + K)

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(LP_TPB) void k_local_search_t(const CkMatern* __res
     const double *u0 = su, *u1 = su + L.npad, *u2 = su + 2 * L.npad;
     const double q0 = pu[p], q1 = pu[mpad + p], q2 = pu[2 * mpad + p];
     double* S = slab + q.off;
-    int* idx = reinterpret_cast<int*>(S + (long)CK_LT_ROWS(kq) * ld + 64 * 64);
+    int* idx = reinterpret_cast<int*>(S + (long)CK_LT_ROWS(kq) * ld + CK_LT_NINV * 64 * 64);
     int base = 0, k0 = 0;   // k0: neighbours of process 0
     for (long g0 = 0; g0 < L.nend; g0 += LP_TPB) {   // ordered compaction, as in k_local_solve
         if (lp_chunk_far(R, g0 / LP_TPB, q0, q1, q2)) continue;   // uniform
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(LT_TPB, 4) void k_local_assemble_t(const CkMatern* 
         const int k = q.k, k0 = k0in[sidx];
         const long ld = q.ld;
         double* S = slab + q.off;
-        const int* idx = reinterpret_cast<const int*>(S + (long)CK_LT_ROWS(q.kq) * ld + 64 * 64);
+        const int* idx = reinterpret_cast<const int*>(S + (long)CK_LT_ROWS(q.kq) * ld + CK_LT_NINV * 64 * 64);
         const int alo = reg == 0 ? 0 : k0, ahi = reg == 0 ? k0 : k;
         const int blo = reg == 2 ? k0 : 0, bhi = reg == 2 ? k : k0;
         if (alo >= ahi || blo >= bhi) continue;   // uniform
