@@ -244,6 +244,12 @@ int ck_debug_site_order(ck_handle* h, int k, int64_t* perm_out, int64_t n_k);
  * out8[0..5] = microseconds of load | factorisation | scaling + store | inverse of the diagonal 16 x 16 blocks |
  * off-diagonal blocks of the inverse | store of the inverse; [6] / [7] = a whole launch (instrumented / product kernel). */
 int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8);
+/* Where a link of the cooperative panel step's chain (k_panel_coop) spends its time, on a rows x 512 test panel: out64[8 b + k],
+ * b = 1 .. 7 = microseconds (shader clock at 2.4 GHz) from chunk b seeing the pivot chunk's "rows final" flag to k = 1
+ * accumulation done | 2 inverse flag seen | 3 rows solved and stored | 4 drained + rows flag set | 5 diagonal block updated |
+ * 6 factored + inverse stored | 7 drained + flag set; out64[8 b] (b >= 2) = the period between links; out64[0] = the whole
+ * launch (HIP events). */
+int ck_debug_coop_profile(ck_handle* h, int64_t rows, double* out64);
 /* Raw lane/register -> (row, col) map of v_mfma_f64_16x16x4_f64: out[64*4*3] ints (row, col, k-map check). */
 int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
 /* FP64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, operands in registers,

@@ -2158,6 +2158,49 @@ extern "C" int ck_debug_potrf_profile(ck_handle* h, int iters, double* out8) {
     return 0;
 }
 
+// Where a link of the cooperative panel step's chain spends its time: k_panel_coop on a well-conditioned rows x 512 panel;
+// out[8 * b + k], b = 1 .. 7: microseconds from the moment chunk b saw the pivot chunk's "rows final" flag (k = 0) to
+// k = 1 accumulation done | 2 inverse flag seen | 3 rows solved and stored | 4 drained + rows flag set | 5 diagonal block
+// updated | 6 factored + inverse stored | 7 drained + flag set; out[0] = the whole launch by HIP events, out[1] = shader MHz.
+extern "C" int ck_debug_coop_profile(ck_handle* h, int64_t rows, double* out64) {
+    CHKH(h);
+    if (!out64 || rows < CK_NB || rows % 64) return fail("bad arguments");
+    DevTemps tmp;
+    double *dP = nullptr;
+    long long *dprof = nullptr, *dinfo = nullptr;
+    HIPCHK(tmp.get(&dP, (size_t)(rows * CK_NB + CK_PANEL_TAIL) * 8));
+    HIPCHK(tmp.get(&dprof, 64 * 8));
+    HIPCHK(tmp.get(&dinfo, 8));
+    std::vector<double> A((size_t)rows * CK_NB);
+    for (int64_t i = 0; i < rows; ++i)
+        for (int j = 0; j < CK_NB; ++j) A[(size_t)i * CK_NB + j] = (i == j ? 600.0 : 0.0) + 1.0 / (1.0 + (double)(i % 977) + j);
+    long long hp[64];
+    float ms = 0;
+    for (int it = 0; it < 3; ++it) {
+        HIPCHK(hipMemcpyAsync(dP, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(dinfo, 0, 8, h->stream));
+        HIPCHK(hipMemsetAsync(dprof, 0, 64 * 8, h->stream));
+        h->coop_seq += 1;
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        ck_launch_panel_coop_prof(h->stream, dP, rows, dP + rows * CK_NB, 0, dinfo, h->d_coop, h->coop_seq, h->d_coop + 16, dprof);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    }
+    HIPCHK(hipGetLastError());
+    // the chain from link 1's first stamp to link 7's last takes (launch - head - tail); the stamps tick at the shader clock:
+    // calibrate it on the span of the whole chain against the event time is too coarse -- report ticks / 2 400 MHz
+    const double mhz = 2400.0;
+    for (int k = 0; k < 64; ++k) out64[k] = 0.0;
+    for (int b = 1; b <= 7; ++b)
+        for (int k = 1; k < 8; ++k) out64[8 * b + k] = (double)(hp[8 * b + k] - hp[8 * b]) / mhz;
+    for (int b = 2; b <= 7; ++b) out64[8 * b] = (double)(hp[8 * b] - hp[8 * (b - 1)]) / mhz;   // link-to-link period
+    out64[0] = (double)ms * 1e3;
+    out64[1] = mhz;
+    return 0;
+}
+
 extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
     CHKH(h);
     int32_t* d = nullptr;

@@ -86,6 +86,9 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
 // that hand each other the pivot blocks through flags[0..7] == seq (ck_la.hip: k_panel_coop); *err != 0: a wait timed out
 void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,
                           unsigned seq, unsigned* err);
+// diagnostic: the cooperative panel step with shader-clock stamps of its links 1 .. 7 (prof: 64 words)
+void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
+                               unsigned* flags, unsigned seq, unsigned* err, long long* prof);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
                          int nJ, int64_t mrows, int64_t nvalid);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur

@@ -645,6 +645,17 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // operations applied to an identity -- 35 us.)
 // Linv: 64 x 64 row-major, lower triangle, upper zero.
 // Lt, Wi: two 64 x 66 LDS arrays (Lt[c][i] = L[i][c]; Wi = the inverse, row-major) owned by the calling kernel
+// PUB: what this call stores will be read by OTHER workgroups of the same launch: write-through (sc1) stores, so that the
+// publisher only has to drain its stores (s_waitcnt vmcnt(0)) in front of the flag instead of writing back its XCD's L2
+// (agent-scope release fence: 1.7 - 6.5 us each, MI355X_MICROARCH.md "inter-workgroup visibility")
+template <bool PUB>
+__device__ __forceinline__ void st_shared_result(double* p, double v) {
+    if (PUB)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
 #define CK_POTRF_MARK(k)                                                            \
     if (PROF) {                                                                     \
         __syncthreads();                                                            \
@@ -654,7 +665,8 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // COLS4: four columns per barrier (the latency-bound uses: one diagonal block at a time in the joint path's panel chain)
 // or one (the local predictor's batched diagonal blocks, thousands of workgroups per launch: THROUGHPUT counts there, and
 // the four-column form's redundant in-register elimination makes every workgroup do more: 10.8 -> 12.5 ms per 400 km run)
-template <bool PROF = false, bool COLS4 = true>
+// PUB: the inverse is read by other workgroups of the same launch (k_panel_coop): write-through stores (st_shared_result)
+template <bool PROF = false, bool COLS4 = true, bool PUB = false>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, long g0, long long* info,
                                              double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66],
                                              long long* prof = nullptr) {
@@ -863,7 +875,7 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
     // out: 64 x 64 row-major, the blocks above the diagonal are zero
     for (int idx = t; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
-        Linv[idx] = ((c >> 4) <= (r >> 4)) ? Wi[r][c] : 0.0;
+        st_shared_result<PUB>(Linv + idx, ((c >> 4) <= (r >> 4)) ? Wi[r][c] : 0.0);
     }
     CK_POTRF_MARK(6)
 }
@@ -959,7 +971,7 @@ __device__ __forceinline__ double ld_shared_result(const double* p) {
     return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
-template <bool SOLVE, bool COH = false>
+template <bool SOLVE, bool COH = false, bool PUB = false>
 __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const double* __restrict__ Ar, long ld,
                                              const double* __restrict__ Br, long ldb, int i,
                                              const double* __restrict__ Linv, double* As, double* Bs) {
@@ -1032,7 +1044,7 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * w + li) * PITCH + 4 * s2 + g],
                                                       Bs[(16 * jt + li) * PITCH + 4 * s2 + g], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = acc[r];
+        for (int r = 0; r < 4; ++r) st_shared_result<PUB>(C + (long)(16 * w + g + 4 * r) * ld + 16 * jt + li, acc[r]);
     }
 }
 
@@ -1192,8 +1204,13 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const doub
 // their solved rows, potrf64_body, release fence, flag.  Everything else that 24 dependent launches per panel did --
 // 8 x (64 x 64 Cholesky + inverse, row solves, K = 64 update), each waiting for the whole previous one -- happens inside
 // this launch with only the true dependencies: a chunk waits for the ONE chunk above it in the chain, not for a
-// grid-wide barrier.  What crosses workgroups (the pivot chunk's rows and its inverse) is read with agent-scope
-// coherent loads; waits are bounded (a timeout sets *err, the host then repeats the factorisation the old way).
+// grid-wide barrier.  What crosses workgroups (the pivot chunk's rows and its inverse) is STORED write-through (sc1) by the
+// eight chunks of the diagonal block, drained (s_waitcnt vmcnt(0)) and announced by one lane's sc1 flag store behind a
+// workgroup barrier; it is READ with sc1 loads after one lane's poll has matched and a workgroup barrier -- the hand-off
+// form of MI355X_MICROARCH.md ("sc1 stores and loads on both sides"): nobody writes back or invalidates a cache (the
+// first version of this kernel published with __threadfence(): ~3.5 us twice per link of the chain).  No workgroup reads
+// a byte of another chunk's rows or of an inverse before its flag, so no XCD's L2 can hold an older copy of them.
+// Waits are bounded (a timeout sets *err, the host then repeats the factorisation the old way).
 #define CK_COOP_SPINS 2000000
 __device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, unsigned* err) {
     __shared__ int ok_s;
@@ -1220,23 +1237,28 @@ __device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, un
 //   coop_finish      X = cn Linv^T once the inverse is published; X goes to memory AND stays in Xs (LDS, 64 x 66) for
 //                    the last slab of the chunk's own diagonal update.
 __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __restrict__ C, const double* __restrict__ Ar,
-                                                long ld, const double* __restrict__ Br, long ldb, int i, double* As,
-                                                double* Bs) {
+                                                const double* __restrict__ Br, int i, double* As, double* Bs) {
+    // (panel-local: every leading dimension is CK_NB, so a thread's sixteen elements of a slab sit at compile-time
+    // offsets from ONE per-thread address -- no pointer arrays in registers)
     constexpr int PITCH = 66;
+    constexpr long LD = CK_NB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
     const int sr = tid >> 6, sc = tid & 63;
+    const double* at = Ar + sr * LD + sc;
+    const double* bt = Br + sr * LD + sc;
+    const double* ct = C + (16 * w + g) * LD + li;
     double ra[16], rb[16];
     if (i > 0) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
-            rb[u] = ld_shared_result<true>(Br + (long)(sr + 4 * u) * ldb + sc);
+            ra[u] = at[4 * u * LD];
+            rb[u] = ld_shared_result<true>(bt + 4 * u * LD);
         }
     }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cn[jt][r] = C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li];
+        for (int r = 0; r < 4; ++r) cn[jt][r] = ct[4 * r * LD + 16 * jt];
     for (int ks = 0; ks < i; ++ks) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -1245,10 +1267,12 @@ __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __r
         }
         __syncthreads();
         if (ks + 1 < i) {
+            at += 64;
+            bt += 64;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
-                rb[u] = ld_shared_result<true>(Br + (long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc);
+                ra[u] = at[4 * u * LD];
+                rb[u] = ld_shared_result<true>(bt + 4 * u * LD);
             }
         }
 #pragma unroll
@@ -1262,9 +1286,11 @@ __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __r
     }
 }
 
-__device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restrict__ C, long ld,
-                                            const double* __restrict__ Linv, double* Xs, double* Bs) {
+template <bool PUB>
+__device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restrict__ C, const double* __restrict__ Linv,
+                                            double* Xs, double* Bs) {
     constexpr int PITCH = 66;
+    constexpr long ld = CK_NB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
     const int sr = tid >> 6, sc = tid & 63;
 #pragma unroll
@@ -1284,7 +1310,7 @@ __device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restr
                                                       acc, 0, 0, 0);
         x[jt] = acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = acc[r];
+        for (int r = 0; r < 4; ++r) st_shared_result<PUB>(C + (long)(16 * w + g + 4 * r) * ld + 16 * jt + li, acc[r]);
     }
     // this wave read only its own 16 rows of Xs (LDS accesses of one wave are served in order): overwrite them with X
 #pragma unroll
@@ -1308,78 +1334,97 @@ __device__ __forceinline__ void coop_slab_syrk(d4_t (&dacc)[4], const double* M)
 }
 
 // flags: [0..7] ready (chunk b published: rows, factored diagonal block, inverse), [8..15] rows (chunk b's rows are final)
-__global__ __launch_bounds__(256, 2) void k_panel_coop(double* P, double* tail, long g0, long long* info, unsigned* flags,
-                                                        unsigned seq, unsigned* err) {
-    __shared__ __attribute__((aligned(16))) double As[64 * 66];
-    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+#define CK_COOP_MARK(k)                                                                      \
+    if (PROF && b >= 1 && b <= 7 && threadIdx.x == 0) prof[8 * b + (k)] = (long long)__builtin_amdgcn_s_memtime();
+// PROF (diagnostic instantiation, ck_debug_coop_profile): shader-clock stamps of the links 1 .. 7 -- [0] rows flag of the
+// pivot chunk seen, [1] accumulation done, [2] inverse flag seen, [3] rows solved and stored, [4] drained + rows flag set,
+// [5] diagonal block updated, [6] factored + inverse stored, [7] drained + flag set
+template <bool PROF, bool DIAG>
+__device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0, long long* info, unsigned* flags,
+                                                unsigned seq, unsigned* err, long long* prof, double* As, double* Bs) {
     constexpr int NQ = CK_NB / 64;
     const int b = (int)blockIdx.x;
     const long row0 = 64 * (long)b;
-    if (b >= NQ) {      // rows below the diagonal block: follow the chain
-        for (int j = 0; j < NQ; ++j) {
-            if (!coop_wait(flags + j, seq, err)) return;      // uniform
-            if (j) __threadfence_block();                     // sub-block j reads what this workgroup stored in sub-blocks < j
-            __syncthreads();
-            lt_rows_body<true, true>(P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
-                                     tail + (long)j * 64 * 64, As, Bs);
-        }
-        return;
-    }
-    // chunk b of the diagonal block: sub-blocks 0 .. b - 2 as above (their pivots were published long ago) ...
-    if (b == 0 && threadIdx.x == 0) __hip_atomic_store(flags + NQ, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no rows
-    for (int j = 0; j + 1 < b; ++j) {
-        if (!coop_wait(flags + j, seq, err)) return;
-        if (j) __threadfence_block();
-        __syncthreads();
-        lt_rows_body<true, true>(P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
-                                 tail + (long)j * 64 * 64, As, Bs);
-    }
-    double* D = P + row0 * CK_NB + 64 * b;
+    const int nj = DIAG ? b : NQ;                   // sub-blocks this chunk is solved against
+    constexpr bool diag = DIAG;                     // a chunk of the diagonal block: a link of the chain
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-    if (b > 0) {
-        // ... sub-block b - 1, whose pivot chunk is the previous link of the chain: everything that needs only that chunk's
-        // ROWS runs while its workgroup factors; the inverse is waited for at the last moment
-        const int j = b - 1;
-        if (!coop_wait(flags + NQ + j, seq, err)) return;
-        __threadfence_block();
+    if (b == 0 && threadIdx.x == 0) __hip_atomic_store(flags + NQ, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // chunk 0 has no rows
+    // Sub-block j in two halves: everything that needs only the pivot chunk's ROWS (the K loop of the update) as soon as
+    // those are final -- a potrf64_body (20 us) before the pivot's inverse exists --, the product with the inverse when
+    // its flag arrives.  A chunk of the diagonal block also folds the rows it has just solved into its own diagonal
+    // update (from LDS), so that behind the last sub-block only one slab and the factorisation are left.
+    d4_t dacc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dacc[jt] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < nj; ++j) {
+        if (!coop_wait(flags + NQ + j, seq, err)) return;      // uniform
+        if (PROF && j == b - 1) CK_COOP_MARK(0)
+        if (j) __threadfence_block();                     // sub-block j reads what this workgroup stored in sub-blocks < j
         __syncthreads();
         d4_t cn[4];
-        coop_accumulate(cn, P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j, As, Bs);
-        // own diagonal block: the slabs of the sub-blocks already solved
-        d4_t dacc[4];
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) dacc[jt] = d4_t{0.0, 0.0, 0.0, 0.0};
-        {
-            const int sr = threadIdx.x >> 6, sc = threadIdx.x & 63;
-            const double* Ar = P + row0 * CK_NB;
-            for (int ks = 0; ks < j; ++ks) {
-                if (ks) __syncthreads();
-#pragma unroll
-                for (int u = 0; u < 16; ++u) As[(sr + 4 * u) * 66 + sc] = Ar[(long)(sr + 4 * u) * CK_NB + 64 * ks + sc];
-                __syncthreads();
-                coop_slab_syrk(dacc, As);
-            }
-            __syncthreads();
-        }
+        coop_accumulate(cn, P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, P + (long)(64 * j) * CK_NB, j, As, Bs);
+        if (PROF && j == b - 1) CK_COOP_MARK(1)
         if (!coop_wait(flags + j, seq, err)) return;
-        coop_finish(cn, P + row0 * CK_NB + 64 * j, CK_NB, tail + (long)j * 64 * 64, As, Bs);
-        // this chunk's rows are final: the next link may start its own accumulation
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flags + NQ + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        coop_slab_syrk(dacc, As);           // last slab: the rows just solved (still in LDS)
+        if (PROF && j == b - 1) CK_COOP_MARK(2)
+        if (diag) {
+            coop_finish<true>(cn, P + row0 * CK_NB + 64 * j, tail + (long)j * 64 * 64, As, Bs);
+            if (PROF && j == b - 1) CK_COOP_MARK(3)
+            if (j == b - 1) {
+                // this chunk's rows are final (every one of them stored write-through): drain the stores, then the next link
+                // may start its own accumulation
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(flags + NQ + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                CK_COOP_MARK(4)
+            }
+            coop_slab_syrk(dacc, As);       // the rows just solved (still in LDS) into the own diagonal update
+        } else {
+            coop_finish<false>(cn, P + row0 * CK_NB + 64 * j, tail + (long)j * 64 * 64, As, Bs);
+        }
+    }
+    if (!diag) return;
+    double* D = P + row0 * CK_NB + 64 * b;
+    if (b > 0) {
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) D[(long)(16 * w + g + 4 * r) * CK_NB + 16 * jt + li] -= dacc[jt][r];
         __threadfence_block();
         __syncthreads();
+        CK_COOP_MARK(5)
     }
     double (*M)[66] = reinterpret_cast<double (*)[66]>(As);
-    potrf64_body(D, CK_NB, g0 + 64 * b, info, tail + (long)b * 64 * 64, M, M);
-    __threadfence();            // release (agent scope): the factored diagonal block and its inverse
+    potrf64_body<false, true, true>(D, CK_NB, g0 + 64 * b, info, tail + (long)b * 64 * 64, M, M);
+    CK_COOP_MARK(6)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the inverse (write-through stores) has left this CU
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flags + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CK_COOP_MARK(7)
+}
+
+__global__ __launch_bounds__(256, 2) void k_panel_coop(double* P, double* tail, long g0, long long* info, unsigned* flags,
+                                                        unsigned seq, unsigned* err) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    if (blockIdx.x < CK_NB / 64)
+        panel_coop_body<false, true>(P, tail, g0, info, flags, seq, err, nullptr, As, Bs);
+    else
+        panel_coop_body<false, false>(P, tail, g0, info, flags, seq, err, nullptr, As, Bs);
+}
+
+__global__ __launch_bounds__(256, 2) void k_panel_coop_prof(double* P, double* tail, long g0, long long* info, unsigned* flags,
+                                                             unsigned seq, unsigned* err, long long* prof) {
+    __shared__ __attribute__((aligned(16))) double As[64 * 66];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
+    if (blockIdx.x < CK_NB / 64)
+        panel_coop_body<true, true>(P, tail, g0, info, flags, seq, err, prof, As, Bs);
+    else
+        panel_coop_body<true, false>(P, tail, g0, info, flags, seq, err, prof, As, Bs);
+}
+
+void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
+                               unsigned* flags, unsigned seq, unsigned* err, long long* prof) {
+    k_panel_coop_prof<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(P, tail, (long)g0, info, flags, seq, err, prof);
 }
 
 void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,

@@ -74,6 +74,7 @@ _PROTOS = {
     "ck_debug_get_entries": [c_void_p, POINTER(c_int64), POINTER(c_int64), c_int64, _dp],
     "ck_debug_mfma_probe": [c_void_p, POINTER(c_int32)],
     "ck_debug_potrf_profile": [c_void_p, c_int, _dp],
+    "ck_debug_coop_profile": [c_void_p, c_int64, _dp],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
@@ -422,6 +423,11 @@ class Handle:
         keys = ["load_us", "factor_us", "scale_store_us", "inv_diag_us", "inv_offdiag_us", "inv_store_us", "launch_prof_us",
                 "launch_us"]
         return dict(zip(keys, out.tolist()))
+
+    def coop_profile(self, rows=4096):
+        out = np.zeros(64)
+        _chk(lib().ck_debug_coop_profile(self._h, int(rows), _p(out)))
+        return out
 
     def mfma_probe(self):
         out = np.empty(64 * 4 * 3, dtype=np.int32)
