@@ -666,7 +666,9 @@ __device__ __forceinline__ void st_shared_result(double* p, double v) {
 // or one (the local predictor's batched diagonal blocks, thousands of workgroups per launch: THROUGHPUT counts there, and
 // the four-column form's redundant in-register elimination makes every workgroup do more: 10.8 -> 12.5 ms per 400 km run)
 // PUB: the inverse is read by other workgroups of the same launch (k_panel_coop): write-through stores (st_shared_result)
-template <bool PROF = false, bool COLS4 = true, bool PUB = false>
+// SRCLDS: the block to factor is handed over in Lt (LDS, row-major, pitch 66) instead of being read from A; the factor is
+// still stored to A
+template <bool PROF = false, bool COLS4 = true, bool PUB = false, bool SRCLDS = false>
 __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, long g0, long long* info,
                                              double* __restrict__ Linv, double (*Lt)[66], double (*Wi)[66],
                                              long long* prof = nullptr) {
@@ -681,7 +683,8 @@ __device__ __forceinline__ void potrf64_body(double* __restrict__ A, long ld, lo
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[r][c] = lower ? A[(long)(4 * bi + r) * ld + 4 * bk + c] : 0.0;
+        for (int c = 0; c < 4; ++c) a[r][c] = lower ? (SRCLDS ? Lt[4 * bi + r][4 * bk + c] : A[(long)(4 * bi + r) * ld + 4 * bk + c]) : 0.0;
+    if (SRCLDS) __syncthreads();   // everybody holds its elements before anything is written to Lt / Wi
     if (PROF) {
         double sum = 0;
 #pragma unroll
@@ -1353,9 +1356,14 @@ __device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0
     // those are final -- a potrf64_body (20 us) before the pivot's inverse exists --, the product with the inverse when
     // its flag arrives.  A chunk of the diagonal block also folds the rows it has just solved into its own diagonal
     // update (from LDS), so that behind the last sub-block only one slab and the factorisation are left.
+    // (the diagonal update runs on -D: dacc = -D + sum X X^T, the updated block is -dacc -- loaded here, while nothing
+    // else is going on, and handed to the factorisation through LDS: no read-modify-write of D on the chain)
     d4_t dacc[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) dacc[jt] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            dacc[jt][r] = DIAG ? -P[(row0 + 16 * w + g + 4 * r) * CK_NB + 64 * b + 16 * jt + li] : 0.0;
     for (int j = 0; j < nj; ++j) {
         if (!coop_wait(flags + NQ + j, seq, err)) return;      // uniform
         if (PROF && j == b - 1) CK_COOP_MARK(0)
@@ -1384,17 +1392,15 @@ __device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0
     }
     if (!diag) return;
     double* D = P + row0 * CK_NB + 64 * b;
-    if (b > 0) {
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D[(long)(16 * w + g + 4 * r) * CK_NB + 16 * jt + li] -= dacc[jt][r];
-        __threadfence_block();
-        __syncthreads();
-        CK_COOP_MARK(5)
-    }
     double (*M)[66] = reinterpret_cast<double (*)[66]>(As);
-    potrf64_body<false, true, true>(D, CK_NB, g0 + 64 * b, info, tail + (long)b * 64 * 64, M, M);
+    __syncthreads();                        // the last slab's reads of As are done
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[16 * w + g + 4 * r][16 * jt + li] = -dacc[jt][r];
+    __syncthreads();
+    CK_COOP_MARK(5)
+    potrf64_body<false, true, true, true>(D, CK_NB, g0 + 64 * b, info, tail + (long)b * 64 * 64, M, M);
     CK_COOP_MARK(6)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the inverse (write-through stores) has left this CU
     __syncthreads();
