@@ -8,6 +8,6 @@ print({k: round(v, 2) for k, v in p.items()})
 for rows in (2048, 16384):
     o = h.coop_profile(rows)
     print(f"k_panel_coop on {rows} rows: launch {o[0]:.1f} us; per link (us after the pivot's rows flag): accumulated | inverse flag | solved | rows flag set | "
-          "diag updated | factored | flag set ; period between links")
+          "diag handed over | factored | flag set")
     for b in range(1, 8):
-        print("  link", b, " ".join(f"{o[8 * b + k]:7.2f}" for k in range(1, 8)), " | period", f"{o[8 * b]:.2f}")
+        print("  link", b, " ".join(f"{o[8 * b + k]:7.2f}" for k in range(1, 8)))   # (stamps of different links come from different XCDs' clocks)
