@@ -259,6 +259,22 @@ int ck_debug_mfma_probe(ck_handle* h, int32_t* out_host);
  * unmasked stream): out[wg] = xcc_id << 16 | se_id << 8 | sh_id << 4 | cu_id from HW_REG_XCC_ID / HW_REG_HW_ID. */
 int ck_debug_cu_probe(ck_handle* h, const uint32_t* cu_mask8, int n_wg, uint32_t* out_host);
 int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3 /* TFLOP/s, shader MHz, cycles per MFMA per wave */);
+/* The clock the chip holds under the Cholesky trailing-update kernel on the data of the last ck_factor (the chip lowers
+ * its clock under load, by an amount that depends on the operands).  Needs option "gemm_stamps" = 1 (set after the first
+ * ck_assemble_joint; the factorisation then runs a stamped instantiation of k_syrk_group_d): out6 = median, 5 % and 95 %
+ * quantile of the in-kernel shader clock in MHz over the stamped workgroups, their number, a workgroup's median
+ * lifetime in shader cycles and in microseconds. */
+int ck_debug_gemm_clock(ck_handle* h, double* out6);
+/* Host only (no device needed): the 128 x 128 tiles of one Cholesky trailing update -- block columns J0 + u Jstep, u < nJ,
+ * of a matrix whose rows / columns from nvalid on are identity padding -- in the order the launch's workgroups take them
+ * (csrc/ck_tilemap.h): out3[3 t .. 3 t + 2] = block column, tile row and tile column inside it, for t < min(total, cap).
+ * Returns the number of tiles = the launch's grid size, or -1. */
+int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, int32_t* out3, int64_t cap);
+/* Raw stamps of the last stamped launch ("gemm_stamps" = 1: every launch, = 2 + K0: only the trailing update behind the
+ * panel group that starts at K0): out[4 b .. 4 b + 3] = shader cycles and 100 MHz ticks of workgroup b's lifetime (0, 0 if
+ * it returned at once), its start in 100 MHz ticks, XCC_ID << 32 | HW_ID; grid4 = grid x, grid y, first block column,
+ * number of panels of that launch. */
+int ck_debug_gemm_stamps(ck_handle* h, uint64_t* out_host, int64_t n_words, int64_t* grid4);
 /* Stage timings of the last calls in milliseconds (HIP events):
  * [0] assemble Sigma, [1] factor, [2] assemble aux, [3] solve sweep, [4] reduce,
  * and, with option "time_gemm": [5]/[6] total ms / number of the Cholesky trailing-update

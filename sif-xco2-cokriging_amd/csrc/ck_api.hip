@@ -27,6 +27,7 @@
 #include "../../include/cokrige.h"
 #include "ck_host.h"
 #include "ck_internal.h"
+#include "ck_tilemap.h"
 #include "ck_model.h"
 
 static int64_t roundup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -193,6 +194,10 @@ struct ck_handle {
     int lookahead = -1;
     // the cooperative panel step (ck_la.hip: k_panel_coop, option "panel_fused" bit 4): [0..15] its flags, [16] its error word
     unsigned* d_coop = nullptr;
+    unsigned long long* d_stamps = nullptr;   // option "gemm_stamps": lifetime stamps of the trailing-update workgroups
+    size_t n_stamps = 0;                      // (ck_debug_gemm_clock), 4 words per workgroup of the largest launch
+    int64_t stamp_grid[4] = {0, 0, 0, 0};     // grid x, y, J0, panels of the last stamped launch
+    int stamp_sel = 0;                        // 1: every launch | >= 2: only the trailing launch behind panel group K0 = stamp_sel - 2
     unsigned coop_seq = 0;
 };
 
@@ -300,6 +305,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->d_coop) (void)hipFree(h->d_coop);
+    if (h->d_stamps) (void)hipFree(h->d_stamps);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -766,7 +772,18 @@ static void gemm_timed_collect(ck_handle* h, int slot) {
 // ---- the building blocks, on an explicit stream --------------------------------------------------
 // two-level panel step on block column K: 8 x (64 x 64 Cholesky, row solves, K = 64 update)
 static void syrk_update(ck_handle* h, hipStream_t st, int K0, int np, int J0, int Jstep, int nJ) {
-    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend);
+    unsigned long long* stamps = nullptr;
+    if (h->d_stamps) {   // diagnostic: only launches that fit the stamp buffer are stamped
+        const size_t wgs = (size_t)((h->Npad - (int64_t)J0 * CK_NB) / 128) * (CK_NB / 128) * (size_t)nJ;
+        if (wgs <= h->n_stamps && (h->stamp_sel == 1 || (nJ > 1 && K0 == h->stamp_sel - 2))) {
+            stamps = h->d_stamps;
+            h->stamp_grid[0] = (int64_t)ck_tilemap_make(h->nend, J0, Jstep, nJ).total;   // the launch's grid: one row
+            h->stamp_grid[1] = 1;
+            h->stamp_grid[2] = J0;
+            h->stamp_grid[3] = np;
+        }
+    }
+    ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend, stamps);
 }
 
 static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
@@ -2278,9 +2295,68 @@ extern "C" int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, d
     return 0;
 }
 
+// Diagnostic: the clock the chip holds under the trailing-update kernel on the data of the last factorisation.  With
+// option "gemm_stamps" = 1 every workgroup of k_syrk_group_d leaves the shader cycles and 100 MHz ticks of its
+// lifetime; out6 = median / 5 % / 95 % quantile of the shader clock in MHz over the stamped workgroups, their number,
+// the median lifetime in shader cycles and in microseconds.
+extern "C" int ck_debug_gemm_clock(ck_handle* h, double* out6) {
+    CHKH(h);
+    if (!h->d_stamps) return fail("ck_debug_gemm_clock: set option gemm_stamps = 1 and factor first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> st(4 * h->n_stamps);
+    HIPCHK(hipMemcpy(st.data(), h->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> mhz, cyc;
+    for (size_t b = 0; b < h->n_stamps; ++b)
+        if (st[4 * b + 1] > 1000) {   // > 10 us: a workgroup that ran a tile
+            mhz.push_back((double)st[4 * b] / (double)st[4 * b + 1] * 100.0);
+            cyc.push_back((double)st[4 * b]);
+        }
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (mhz.empty()) return 0;
+    std::sort(mhz.begin(), mhz.end());
+    std::sort(cyc.begin(), cyc.end());
+    out6[0] = mhz[mhz.size() / 2];
+    out6[1] = mhz[mhz.size() / 20];
+    out6[2] = mhz[mhz.size() - 1 - mhz.size() / 20];
+    out6[3] = (double)mhz.size();
+    out6[4] = cyc[cyc.size() / 2];
+    out6[5] = out6[4] / out6[0];
+    return 0;
+}
+
+// raw stamps of the last stamped launch: out[4 b .. 4 b + 3] = shader cycles, 100 MHz ticks of workgroup b's lifetime (0, 0
+// if it returned at once), its start in 100 MHz ticks, XCC_ID << 32 | HW_ID; grid4 = grid x, y, first block column, panels
+extern "C" int ck_debug_gemm_stamps(ck_handle* h, uint64_t* out_host, int64_t n_words, int64_t* grid4) {
+    CHKH(h);
+    if (!h->d_stamps) return fail("ck_debug_gemm_stamps: set option gemm_stamps and factor first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = std::min<size_t>((size_t)std::max<int64_t>(n_words, 0), 4 * h->n_stamps);
+    HIPCHK(hipMemcpy(out_host, h->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) grid4[i] = h->stamp_grid[i];
+    return 0;
+}
+
 extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     CHKH(h);
     if (!name) return fail("null option name");
+    if (!strcmp(name, "gemm_stamps")) {   // diagnostic, see ck_debug_gemm_clock; after the first assemble
+        if (h->d_stamps) {
+            (void)hipFree(h->d_stamps);
+            h->d_stamps = nullptr;
+            h->n_stamps = 0;
+        }
+        if (value != 0) {
+            if (!h->layout_ready) return fail("gemm_stamps: assemble first");
+            HIPCHK(hipSetDevice(h->device));
+            h->n_stamps = (size_t)(h->Npad / 128) * (CK_NB / 128) * (size_t)(h->Npad / CK_NB);
+            HIPCHK(hipMalloc((void**)&h->d_stamps, 4 * h->n_stamps * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(h->d_stamps, 0, 4 * h->n_stamps * sizeof(unsigned long long)));
+        }
+        h->stamp_sel = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "time_gemm")) {
         if (value < 0 || value > 2) return fail("time_gemm must be 0, 1 or 2");
         h->time_gemm = (int)value;

@@ -1,5 +1,6 @@
 // ck_host.cpp -- see ck_host.h.  Nothing in this file touches the GPU.
 #include "ck_host.h"
+#include "ck_tilemap.h"
 
 #include <math.h>
 #include <string.h>
@@ -187,6 +188,22 @@ extern "C" int ck_hilbert_order(const double* coords, int64_t n, int64_t* perm_o
     ck_host_hilbert_order(coords, n, lo, hi, perm);
     memcpy(perm_out, perm.data(), (size_t)n * sizeof(int64_t));
     return 0;
+}
+
+// host-only: the tiles of one Cholesky trailing update in launch order (ck_tilemap.h; tests/test_tilemap.py)
+extern "C" int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, int32_t* out3, int64_t cap) {
+    if (nvalid <= 0 || J0 < 0 || Jstep < 1 || nJ < 0) return ck_fail("bad arguments");
+    if (4LL * J0 >= (nvalid + 127) / 128) return ck_fail("block column J0 lies in the padding");
+    const CkTileMap m = ck_tilemap_make(nvalid, J0, Jstep, nJ);
+    if (out3)
+        for (int64_t t = 0; t < m.total && t < cap; ++t) {
+            int u, tm, tn;
+            ck_tilemap_get(m, t, u, tm, tn);
+            out3[3 * t] = J0 + u * Jstep;
+            out3[3 * t + 1] = tm;
+            out3[3 * t + 2] = tn;
+        }
+    return m.total;
 }
 
 extern "C" int ck_ref_distance(int metric, const double* A, const double* B, int64_t n, double* out) {

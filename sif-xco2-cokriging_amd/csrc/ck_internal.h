@@ -81,7 +81,8 @@ void ck_launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, i
 // (device pointer table sigptr_dev[J], panel P = rows K*NB.. of L).
 void ck_launch_cu_probe(hipStream_t s, unsigned* out, int n_wg, int spin);
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */);
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid /* rows / columns from here on are identity padding */,
+                          unsigned long long* stamps = nullptr /* diagnostic: ck_debug_gemm_clock */);
 // the whole panel step (diagonal blocks, inverses, row solves, panel-internal updates) in ONE launch: nrows / 64 workgroups
 // that hand each other the pivot blocks through flags[0..7] == seq (ck_la.hip: k_panel_coop); *err != 0: a wait timed out
 void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,

@@ -16,6 +16,7 @@
 // All matrices are row-major.  Dimensions handed to these kernels are padded by the host (ck_api.hip) so that no
 // edge predication is needed in the hot loops.
 #include "ck_internal.h"
+#include "ck_tilemap.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -500,25 +501,41 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         }
 }
 
-template <int WAVES>
+// STAMP (diagnostic, ck_debug_gemm_clock / ck_debug_gemm_stamps): thread 0 of every workgroup leaves the shader cycles and
+// the 100 MHz ticks of its lifetime in stamps[4 b], stamps[4 b + 1], then its start in 100 MHz ticks and XCC_ID << 32 |
+// HW_ID.  cycles / ticks is the clock the chip holds under this kernel on this data (MI355X lowers its clock under load
+// by an amount that depends on the operands: MI355X_MICROARCH.md, "DVFS give-back"); starts and lifetimes show how many
+// of the chip's 512 tile slots are occupied over a launch.
+template <int WAVES, bool STAMP = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d(double* const* __restrict__ sigptr,
-                                                         double* const* __restrict__ srcptr, int K0, int np, int J0,
-                                                         int Jstep, long Npad, long nvalid) {
+                                                         double* const* __restrict__ srcptr, int K0, int np,
+                                                         const CkTileMap map,
+                                                         unsigned long long* __restrict__ stamps = nullptr) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int J = J0 + (int)blockIdx.y * Jstep;
-    const long M = Npad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    unsigned long long t0 = 0, q0 = 0;
+    if (STAMP) {
+        t0 = __builtin_amdgcn_s_memtime();
+        q0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // one workgroup per tile, none that returns at once (ck_tilemap.h); every XCD a contiguous run of the launch's tiles
+    int u, tm, tn;
+    ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
+    const int J = map.J0 + u * map.Jstep;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
-    if (r0 + 127 < c0) return;
-    // tiles entirely inside the identity padding behind the last site (up to 511 rows / columns): a padded row of L is
-    // zero left of its diagonal, so their update is exactly zero
-    if ((long)J * CK_NB + r0 >= nvalid || (long)J * CK_NB + c0 >= nvalid) return;
     const CkSrcSyrk src{srcptr, K0, J, r0, c0};
     gemm_tile_d<WAVES>(sigptr[J], CK_NB, src, np, r0, c0, lds);
+    if (STAMP) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            const size_t b = blockIdx.x;
+            stamps[4 * b] = t1 - t0;
+            stamps[4 * b + 1] = q1 - q0;
+            stamps[4 * b + 2] = q0;
+            stamps[4 * b + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+        }
+    }
 }
 
 template <int WAVES>
@@ -580,11 +597,16 @@ void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double*
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the
 // block-column-cyclic stride of a multi-process run
 void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* const* srcptr_dev, int K0, int np, int J0,
-                          int Jstep, int nJ, int64_t Npad, int64_t nvalid) {
+                          int Jstep, int nJ, int64_t Npad, int64_t nvalid, unsigned long long* stamps) {
     if (nJ <= 0 || np <= 0) return;
-    const int64_t M0 = Npad - (int64_t)J0 * CK_NB;
-    const dim3 grid((unsigned)((M0 / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, J0, Jstep, Npad, nvalid);
+    (void)Npad;
+    const CkTileMap map = ck_tilemap_make(nvalid, J0, Jstep, nJ);
+    if (map.total <= 0) return;
+    const dim3 grid((unsigned)map.total);
+    if (stamps)
+        k_syrk_group_d<8, true><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, map, stamps);
+    else
+        k_syrk_group_d<8><<<grid, dim3(512), 0, s>>>(sigptr_dev, srcptr_dev, K0, np, map);
 }
 
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out

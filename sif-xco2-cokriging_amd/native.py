@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import numpy as np
 
@@ -76,6 +76,9 @@ _PROTOS = {
     "ck_debug_potrf_profile": [c_void_p, c_int, _dp],
     "ck_debug_coop_profile": [c_void_p, c_int64, _dp],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
+    "ck_debug_gemm_clock": [c_void_p, _dp],
+    "ck_debug_tile_map": [c_int64, c_int, c_int, c_int, POINTER(c_int32), c_int64],
+    "ck_debug_gemm_stamps": [c_void_p, POINTER(c_uint64), c_int64, POINTER(c_int64)],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
     "ck_timings": [c_void_p, _dp, c_int],
@@ -117,6 +120,9 @@ def _preload_hip_runtime():
             pass
 
 
+_RET_INT64 = {"ck_debug_tile_map"}
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -130,7 +136,7 @@ def lib():
         L.ck_last_error.argtypes = []
         for name, args in _PROTOS.items():
             fn = getattr(L, name)
-            fn.restype = c_int
+            fn.restype = c_int64 if name in _RET_INT64 else c_int
             fn.argtypes = args
         _lib = L
     return _lib
@@ -160,6 +166,18 @@ def ref_distance(metric: int, A, B):
         raise ValueError("A and B must have the same shape")
     out = np.empty(A.shape[0])
     _chk(lib().ck_ref_distance(int(metric), _p(A), _p(B), A.shape[0], _p(out)))
+    return out
+
+
+def tile_map(nvalid: int, J0: int, Jstep: int, nJ: int):
+    """(block column, tile row, tile column) of every workgroup of one Cholesky trailing update, in launch order
+    (include/cokrige.h: ck_debug_tile_map; host only)."""
+    n = lib().ck_debug_tile_map(int(nvalid), int(J0), int(Jstep), int(nJ), None, 0)
+    if n < 0:
+        _chk(-1)
+    out = np.zeros((n, 3), dtype=np.int32)
+    if n:
+        lib().ck_debug_tile_map(int(nvalid), int(J0), int(Jstep), int(nJ), out.ctypes.data_as(POINTER(c_int32)), n)
     return out
 
 
@@ -461,6 +479,21 @@ class Handle:
         out = np.zeros(3)
         _chk(lib().ck_debug_mfma_peak(self._h, int(waves_per_simd), int(iters), _p(out)))
         return dict(tflops=out[0], shader_mhz=out[1], cycles_per_mfma_per_wave=out[2])
+
+    def gemm_clock(self):
+        """After set_option("gemm_stamps", 1) and a factorisation: the in-kernel clock of the trailing updates."""
+        out = np.zeros(6)
+        _chk(lib().ck_debug_gemm_clock(self._h, _p(out)))
+        return dict(mhz_median=out[0], mhz_p05=out[1], mhz_p95=out[2], workgroups=int(out[3]),
+                    wg_cycles_median=out[4], wg_us_median=out[5])
+
+    def gemm_stamps(self, n_workgroups):
+        """Raw workgroup stamps of the last stamped trailing update: (n, 4) uint64 and (grid x, grid y, J0, panels)."""
+        out = np.zeros((int(n_workgroups), 4), dtype=np.uint64)
+        grid = np.zeros(4, dtype=np.int64)
+        _chk(lib().ck_debug_gemm_stamps(self._h, out.ctypes.data_as(POINTER(c_uint64)), out.size,
+                                        grid.ctypes.data_as(POINTER(c_int64))))
+        return out, grid
 
     def timings(self):
         out = np.zeros(14)

@@ -1,0 +1,51 @@
+"""The workgroup -> tile map of the Cholesky trailing updates (csrc/ck_tilemap.h, host side through ck_debug_tile_map):
+every launch must cover exactly the tiles the rectangular grid of rounds 1-3 did not skip -- on or below the diagonal of
+its block column, rows and columns in front of the identity padding -- once each, column by column, row by row."""
+import numpy as np
+import pytest
+
+from sif_xco2_cokriging_amd import native
+
+
+def brute(nvalid, J0, Jstep, nJ):
+    Npad = (nvalid + 511) // 512 * 512
+    out = []
+    for y in range(nJ):
+        J = J0 + y * Jstep
+        M = Npad - J * 512
+        for tm in range(max(M, 0) // 128):
+            for tn in range(4):
+                r0, c0 = tm * 128, tn * 128
+                if r0 + 127 < c0:
+                    continue
+                if J * 512 + r0 >= nvalid or J * 512 + c0 >= nvalid:
+                    continue
+                out.append((J, tm, tn))
+    return np.array(out, dtype=np.int32).reshape(-1, 3)
+
+
+CASES = []
+for nvalid in (1, 100, 128, 129, 300, 384, 385, 512, 513, 700, 1024, 4600, 9984, 10000, 40000, 40064, 100096):
+    nK = (nvalid + 511) // 512
+    for J0 in sorted({0, 1, 2, nK // 2, nK - 2, nK - 1}):
+        if J0 < 0 or J0 >= nK:
+            continue
+        for Jstep in (1, 2, 3, 8):
+            full = (nK - 1 - J0) // Jstep + 1
+            for nJ in sorted({1, 2, full - 1, full}):
+                if 1 <= nJ <= full:
+                    CASES.append((nvalid, J0, Jstep, nJ))
+
+
+def test_tile_map_covers_the_lower_triangle_exactly_once():
+    assert len(CASES) > 300
+    for nvalid, J0, Jstep, nJ in CASES:
+        got = native.tile_map(nvalid, J0, Jstep, nJ)
+        want = brute(nvalid, J0, Jstep, nJ)
+        assert got.shape == want.shape, (nvalid, J0, Jstep, nJ, got.shape, want.shape)
+        assert np.array_equal(got, want), (nvalid, J0, Jstep, nJ)
+
+
+def test_tile_map_rejects_a_first_column_inside_the_padding():
+    with pytest.raises(native.NativeError):
+        native.tile_map(1000, 2, 1, 1)
