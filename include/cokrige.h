@@ -270,6 +270,10 @@ int ck_debug_gemm_clock(ck_handle* h, double* out6);
  * (csrc/ck_tilemap.h): out3[3 t .. 3 t + 2] = block column, tile row and tile column inside it, for t < min(total, cap).
  * Returns the number of tiles = the launch's grid size, or -1. */
 int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, int32_t* out3, int64_t cap);
+/* Host only: the workgroups of a batched launch of the local predictor's tiled path over n_sys systems, largest first, with
+ * counts[y] work units each (non-increasing): out2[2 b], out2[2 b + 1] = system (-1: a padding workgroup at the end of a
+ * run of equal counts) and unit of workgroup b, for b < min(grid, cap).  Returns the grid size, or -1. */
+int64_t ck_debug_run_map(const int32_t* counts, int n_sys, int32_t* out2, int64_t cap);
 /* Raw stamps of the last stamped launch ("gemm_stamps" = 1: every launch, = 2 + K0: only the trailing update behind the
  * panel group that starts at K0): out[4 b .. 4 b + 3] = shader cycles and 100 MHz ticks of workgroup b's lifetime (0, 0 if
  * it returned at once), its start in 100 MHz ticks, XCC_ID << 32 | HW_ID; grid4 = grid x, grid y, first block column,

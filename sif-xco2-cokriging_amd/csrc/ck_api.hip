@@ -1709,18 +1709,20 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
                                        layout_of(h), bsys, nb, d_slab, h->d_tabs, h->d_coefptr, use_tab, h->su, d_pu,
                                        h->d_chunkb, cmax, d_k0 + tb.first);
             const int kq_max = sysv[tb.first].kq;
+            std::vector<int> kqv(nb);
+            for (int y = 0; y < nb; ++y) kqv[y] = sysv[tb.first + y].kq;
             int na = nb;
             const int G = h->local_group;
             for (int g0 = 0; g0 < kq_max; g0 += 64 * G) {
                 // the group's diagonal region block by block (diagonal block, then the few chunks of rows inside the region) ...
                 for (int b = 0; b < G && g0 + 64 * b < kq_max; ++b) {
                     while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * b) --na;   // finished systems drop off the end
-                    ck_launch_local_tiled_block(h->stream, bsys, d_slab, na, g0, b, kq_max, d_linfo + tb.first, G);
+                    ck_launch_local_tiled_block(h->stream, bsys, d_slab, na, g0, b, kqv.data(), d_linfo + tb.first, G);
                 }
                 // ... then every row below it through all of the group's blocks in one launch, then the trailing update
                 while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * G) --na;
-                ck_launch_local_tiled_rows_all(h->stream, bsys, d_slab, na, g0, G, kq_max);
-                ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kq_max);
+                ck_launch_local_tiled_rows_all(h->stream, bsys, d_slab, na, g0, G, kqv.data());
+                ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kqv.data());
             }
             ck_launch_local_reduce_t(h->stream, bsys, nb, d_slab, d_linfo + tb.first, c0var, d_out, d_out + mp);
             HIPCHK(hipGetLastError());

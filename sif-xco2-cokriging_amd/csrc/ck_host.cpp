@@ -206,6 +206,23 @@ extern "C" int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, 
     return m.total;
 }
 
+// host-only: workgroup -> (system, unit) of a batched launch over systems with counts[y] units each (ck_tilemap.h)
+extern "C" int64_t ck_debug_run_map(const int32_t* counts, int n_sys, int32_t* out2, int64_t cap) {
+    if (n_sys < 0 || (n_sys > 0 && !counts)) return ck_fail("bad arguments");
+    for (int y = 1; y < n_sys; ++y)
+        if (counts[y] > counts[y - 1]) return ck_fail("counts must not increase");
+    const CkRunMap m = ck_runmap_make(n_sys, [&](int y) { return (int)counts[y]; });
+    const int64_t total = m.nruns ? m.off[m.nruns] : 0;
+    if (out2)
+        for (int64_t b = 0; b < total && b < cap; ++b) {
+            int y, t;
+            const bool real = ck_runmap_get(m, (int)b, y, t);
+            out2[2 * b] = real ? y : -1;
+            out2[2 * b + 1] = t;
+        }
+    return total;
+}
+
 extern "C" int ck_ref_distance(int metric, const double* A, const double* B, int64_t n, double* out) {
     if (metric != CK_HOST_METRIC_HAVERSINE && metric != CK_HOST_METRIC_EUCLID) return ck_fail("unknown metric");
     if (n > 0 && (!A || !B || !out)) return ck_fail("null array");

@@ -215,11 +215,13 @@ void ck_launch_local_assemble_t(hipStream_t s, const CkMatern* blk, int metric, 
 // read-modify-write traffic of updating after every block).  Systems sorted by k descending: the first n_active
 // are the ones that still have the block / trailing columns in question.
 void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
-                                 int kq_max, long long* info, int group_blocks);
+                                 const int* kq_host, long long* info, int group_blocks);
 // the rows BELOW the group's diagonal region, through all of the group's blocks in one launch (group_blocks of them)
+// kq_host: the padded sizes of the batch's systems on the host (largest first): the launches have exactly one workgroup
+// per chunk / tile that exists (ck_tilemap.h)
 void ck_launch_local_tiled_rows_all(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0,
-                                    int group_blocks, int kq_max);
+                                    int group_blocks, const int* kq_host);
 void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
-                                    int kq_max);
+                                    const int* kq_host);
 void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,
                               const long long* info, double c0var, double* pred, double* err);

@@ -1131,16 +1131,18 @@ __global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict
 // row solve, step by step with the diagonal blocks (k_lt_potrf64) -- these few chunks are what the next diagonal block
 // waits for.  The rows below the region go through all of the group's blocks at once afterwards (k_lt_rows_all).
 __global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
-                                                     int i, int gb) {
+                                                     int i, int gb, const CkRunMap map) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
-    const CkLocalSys q = sys[blockIdx.y];
+    int y, chunk;
+    if (!ck_runmap_get(map, (int)blockIdx.x, y, chunk)) return;
+    const CkLocalSys q = sys[y];
     const int jb = g0 + 64 * i;
     const int lim = q.kq < g0 + 64 * gb ? q.kq : g0 + 64 * gb;
     const int nchunk = (lim - jb - 64) / 64;   // rows jb + 64 .. lim - 1
-    if ((int)blockIdx.x >= nchunk) return;
+    if (chunk >= nchunk) return;
     double* S = slab + q.off;
-    const long row0 = jb + 64 + 64 * (long)blockIdx.x;
+    const long row0 = jb + 64 + 64 * (long)chunk;
     lt_rows_body<true>(S + row0 * q.ld + jb, S + row0 * q.ld + g0, q.ld, S + (long)jb * q.ld + g0, q.ld, i,
                        S + (long)CK_LT_ROWS(q.kq) * q.ld + (long)i * 64 * 64, As, Bs);
 }
@@ -1152,15 +1154,17 @@ __global__ __launch_bounds__(256, 2) void k_lt_rows(const CkLocalSys* __restrict
 // by every later block of the group (64 i columns at block i: 448 KB -> 256 KB per chunk and group of four), and the
 // launches of a group drop from 2 gb to gb + (gb - 1) + 1, the big ones from gb to one.
 __global__ __launch_bounds__(256, 2) void k_lt_rows_all(const CkLocalSys* __restrict__ sys, double* __restrict__ slab,
-                                                         int g0, int gb) {
+                                                         int g0, int gb, const CkRunMap map) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
-    const CkLocalSys q = sys[blockIdx.y];
+    int y, chunk;   // one workgroup per chunk that exists (ck_tilemap.h), a system's chunks on one XCD
+    if (!ck_runmap_get(map, (int)blockIdx.x, y, chunk)) return;
+    const CkLocalSys q = sys[y];
     const int r_first = g0 + 64 * gb;
     const int nchunk = (q.kq - r_first) / 64;
-    if ((int)blockIdx.x >= nchunk) return;
+    if (chunk >= nchunk) return;
     double* S = slab + q.off;
-    const long row0 = r_first + 64 * (long)blockIdx.x;
+    const long row0 = r_first + 64 * (long)chunk;
     const double* linv = S + (long)CK_LT_ROWS(q.kq) * q.ld;
     for (int i = 0; i < gb; ++i) {
         if (i) {   // block i reads what other threads of this workgroup stored in the blocks before it
@@ -1478,15 +1482,13 @@ void ck_launch_panel_rows(hipStream_t s, double* X, int64_t row_first, int64_t n
 }
 
 // trailing update behind a group of columns [g0, g0 + K):  C -= A A^T on 128 x 128 tiles, rows and columns
-// g0 + K .. kq - 1, lower tiles only.  All tiles of a system run on one XCD (they share the A rows through
-// its L2): with workgroups dealt out to the 8 XCDs round-robin by linear id, system y' = 8 (id / (8 GX)) + id % 8.
+// g0 + K .. kq - 1, lower tiles only.  One workgroup per tile that exists (ck_tilemap.h: runs of systems with the same
+// number of tiles); all tiles of a system run on one XCD (they share the A rows through its L2).
 __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restrict__ sys, double* __restrict__ slab,
-                                                       int g0, int K, int n_active) {
+                                                       int g0, int K, const CkRunMap map) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int GX = gridDim.x;
-    const int lin = blockIdx.x + blockIdx.y * GX;
-    const int y = 8 * (lin / (8 * GX)) + (lin & 7), t = (lin >> 3) % GX;
-    if (y >= n_active) return;
+    int y, t;
+    if (!ck_runmap_get(map, (int)blockIdx.x, y, t)) return;
     const CkLocalSys q = sys[y];
     const int o = g0 + K;
     const int T = (q.kq - o + 127) / 128;
@@ -1502,28 +1504,34 @@ __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restri
 
 // block i of the group at g0 for the first n_active systems (those with kq > g0 + 64 i)
 void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
-                                 int kq_max, long long* info, int group_blocks) {
+                                 const int* kq_host, long long* info, int group_blocks) {
     if (n_active <= 0) return;
     k_lt_potrf64<<<dim3((unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, info);
-    const int lim = kq_max < g0 + 64 * group_blocks ? kq_max : g0 + 64 * group_blocks;
-    const int rows = lim - (g0 + 64 * i) - 64;   // inside the group's diagonal region only
-    if (rows > 0) k_lt_rows<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, i, group_blocks);
+    const int top = g0 + 64 * group_blocks, jb = g0 + 64 * i;   // rows inside the group's diagonal region only
+    const CkRunMap map = ck_runmap_make(n_active, [&](int y) { return ((kq_host[y] < top ? kq_host[y] : top) - jb - 64) / 64; });
+    if (map.nruns > 0) k_lt_rows<<<dim3((unsigned)map.off[map.nruns]), dim3(256), 0, s>>>(sys, slab, g0, i, group_blocks, map);
 }
 
 void ck_launch_local_tiled_rows_all(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0,
-                                    int group_blocks, int kq_max) {
-    const int rows = kq_max - g0 - 64 * group_blocks;
-    if (n_active <= 0 || rows <= 0) return;
-    k_lt_rows_all<<<dim3((unsigned)(rows / 64), (unsigned)n_active), dim3(256), 0, s>>>(sys, slab, g0, group_blocks);
+                                    int group_blocks, const int* kq_host) {
+    if (n_active <= 0) return;
+    const int r_first = g0 + 64 * group_blocks;
+    const CkRunMap map = ck_runmap_make(n_active, [&](int y) { return (kq_host[y] - r_first) / 64; });
+    if (map.nruns == 0) return;
+    k_lt_rows_all<<<dim3((unsigned)map.off[map.nruns]), dim3(256), 0, s>>>(sys, slab, g0, group_blocks, map);
 }
 
 // trailing update behind the group [g0, g0 + K) for the first n_active systems (those with kq > g0 + K)
 void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
-                                    int kq_max) {
-    if (n_active <= 0 || kq_max - g0 - K <= 0) return;
-    const int T = (kq_max - g0 - K + 127) / 128;
-    k_lt_update<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)((n_active + 7) / 8 * 8)), dim3(512), 0, s>>>(sys, slab, g0, K,
-                                                                                                      n_active);
+                                    const int* kq_host) {
+    if (n_active <= 0) return;
+    const int o = g0 + K;
+    const CkRunMap map = ck_runmap_make(n_active, [&](int y) {
+        const int T = (kq_host[y] - o + 127) / 128;
+        return T > 0 ? T * (T + 1) / 2 : 0;
+    });
+    if (map.nruns == 0) return;
+    k_lt_update<<<dim3((unsigned)map.off[map.nruns]), dim3(512), 0, s>>>(sys, slab, g0, K, map);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -97,3 +97,59 @@ CK_HD void ck_tilemap_get(const CkTileMap& m, long long t, int& u, int& tm, int&
         tn = (int)((local - 6) & 3);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched systems of different sizes (the local predictor's tiled path): workgroup id -> (system, unit inside it)
+// ---------------------------------------------------------------------------------------------------------------
+// The systems of a batch are sorted by size, largest first, so the number of work units a launch has for system y
+// (128 x 128 tiles of its trailing matrix, 64-row chunks below a column group) never grows with y and takes few
+// distinct values: runs of systems with the same count.  Rounds 1-3 launched (units of the LARGEST system) x (systems)
+// and let the surplus return at once -- at 400 km most of the grid.  Here a launch has, per run, exactly
+// count x (systems of the run, rounded up to 8) workgroups; the table of runs travels as a kernel argument.
+// Inside a run the workgroups are dealt out so that all units of a system have the same id modulo 8, i.e. run on one
+// XCD and share its L2 (workgroups go to the XCDs round-robin by linear id; run offsets are multiples of 8).
+#define CK_RUN_MAX 48
+struct CkRunMap {
+    int nruns;
+    int off[CK_RUN_MAX + 1];   // first workgroup of run r; off[nruns] = the grid
+    int y0[CK_RUN_MAX];        // first system of run r
+    int n[CK_RUN_MAX];         // systems in run r
+    int c[CK_RUN_MAX];         // workgroups per system in run r (the largest count inside the run)
+};
+
+// count(y) for y < n_sys, non-increasing; systems with count 0 (a suffix) get no workgroups.  More than CK_RUN_MAX
+// distinct counts: the last run takes the rest with its largest count (the kernels keep their own bound checks).
+template <class F>
+static inline CkRunMap ck_runmap_make(int n_sys, F count) {
+    CkRunMap m;
+    m.nruns = 0;
+    m.off[0] = 0;
+    int y = 0;
+    while (y < n_sys) {
+        const int c = count(y);
+        if (c <= 0) break;
+        int e = y + 1;
+        if (m.nruns == CK_RUN_MAX - 1)
+            while (e < n_sys && count(e) > 0) ++e;
+        else
+            while (e < n_sys && count(e) == c) ++e;
+        const int r = m.nruns++;
+        m.y0[r] = y;
+        m.n[r] = e - y;
+        m.c[r] = c;
+        m.off[r + 1] = m.off[r] + c * ((e - y + 7) / 8 * 8);
+        y = e;
+    }
+    return m;
+}
+
+// workgroup b -> system y and unit t; false: a padding workgroup at the end of a run (at most 7 systems' worth)
+CK_HD bool ck_runmap_get(const CkRunMap& m, int b, int& y, int& t) {
+    int r = 0;
+    while (r + 1 < m.nruns && b >= m.off[r + 1]) ++r;
+    const int L = b - m.off[r], c = m.c[r];
+    const int yl = 8 * (L / (8 * c)) + (L & 7);
+    t = (L >> 3) % c;
+    y = m.y0[r] + yl;
+    return yl < m.n[r];
+}

@@ -78,6 +78,7 @@ _PROTOS = {
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_debug_gemm_clock": [c_void_p, _dp],
     "ck_debug_tile_map": [c_int64, c_int, c_int, c_int, POINTER(c_int32), c_int64],
+    "ck_debug_run_map": [POINTER(c_int32), c_int, POINTER(c_int32), c_int64],
     "ck_debug_gemm_stamps": [c_void_p, POINTER(c_uint64), c_int64, POINTER(c_int64)],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
     "ck_set_option": [c_void_p, c_char_p, c_int64],
@@ -120,7 +121,7 @@ def _preload_hip_runtime():
             pass
 
 
-_RET_INT64 = {"ck_debug_tile_map"}
+_RET_INT64 = {"ck_debug_tile_map", "ck_debug_run_map"}
 
 
 def lib():
@@ -178,6 +179,20 @@ def tile_map(nvalid: int, J0: int, Jstep: int, nJ: int):
     out = np.zeros((n, 3), dtype=np.int32)
     if n:
         lib().ck_debug_tile_map(int(nvalid), int(J0), int(Jstep), int(nJ), out.ctypes.data_as(POINTER(c_int32)), n)
+    return out
+
+
+def run_map(counts):
+    """(system, unit) of every workgroup of a batched launch over systems with `counts` units each, -1 for padding
+    workgroups (include/cokrige.h: ck_debug_run_map; host only)."""
+    c = np.ascontiguousarray(counts, dtype=np.int32)
+    cp = c.ctypes.data_as(POINTER(c_int32))
+    n = lib().ck_debug_run_map(cp, c.size, None, 0)
+    if n < 0:
+        _chk(-1)
+    out = np.zeros((n, 2), dtype=np.int32)
+    if n:
+        lib().ck_debug_run_map(cp, c.size, out.ctypes.data_as(POINTER(c_int32)), n)
     return out
 
 

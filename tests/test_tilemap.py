@@ -49,3 +49,30 @@ def test_tile_map_covers_the_lower_triangle_exactly_once():
 def test_tile_map_rejects_a_first_column_inside_the_padding():
     with pytest.raises(native.NativeError):
         native.tile_map(1000, 2, 1, 1)
+
+
+def test_run_map_of_the_batched_local_systems():
+    """Every (system, unit) with unit < counts[system] exactly once; padding only at the end of runs (< 8 systems' worth
+    each); all units of a system share the workgroup id modulo 8 (one XCD)."""
+    rng = np.random.default_rng(5)
+    cases = [[5], [3, 3, 3], [0], [], [7, 7, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 0, 0],
+             sorted(rng.integers(0, 46, 3000).tolist(), reverse=True),
+             sorted((rng.integers(1, 300, 500) * 7).tolist(), reverse=True),   # more distinct counts than runs in the table
+             sorted([t * (t + 1) // 2 for t in rng.integers(0, 12, 9000)], reverse=True)]
+    for counts in cases:
+        counts = np.asarray(counts, dtype=np.int32)
+        got = native.run_map(counts)
+        real = got[got[:, 0] >= 0]
+        ok = real[:, 1] < counts[real[:, 0]] if len(real) else np.zeros(0, bool)
+        pairs = real[ok]
+        want = np.array([(y, t) for y in range(len(counts)) for t in range(counts[y])], dtype=np.int32).reshape(-1, 2)
+        a = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+        assert np.array_equal(a, want), counts[:10]
+        if len(want):
+            ids = np.nonzero(got[:, 0] >= 0)[0][ok]
+            for y in np.unique(pairs[:, 0])[:50]:
+                assert len(set(ids[pairs[:, 0] == y] % 8)) == 1
+            if len(np.unique(counts[counts > 0])) < 40:
+                assert len(got) <= len(want) + 8 * int(counts[counts > 0].astype(np.int64).max()) * len(np.unique(counts[counts > 0]))
+    with pytest.raises(native.NativeError):
+        native.run_map([1, 2])
