@@ -118,6 +118,14 @@ int ck_factor(ck_handle* h, int64_t* info);
  * pred = V^T y, pred_err = nan_to_num(sqrt(sigma_i^2 + nugget_i - |V_k|^2)) (:68-78).
  * Needs ck_factor; may be called repeatedly. */
 int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host);
+/* ck_factor + ck_predict in one call, for a Sigma that is assembled and not yet factored (Predictor.__call__,
+ * src/joint_prediction.py:60-78, does exactly this sequence): the factorisation and the forward substitution of the
+ * right-hand sides run as two overlapped sweeps, the substitution one panel group behind the factorisation, so that each
+ * fills the other's idle stretches (panel chain, under-filled in-group launches, launch drains).  Same results to rounding,
+ * same *info and error behaviour as ck_factor; *info != 0 leaves pred / pred_err untouched.  The factor stays resident:
+ * further ck_predict calls work as after ck_factor. */
+int ck_factor_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host,
+                      int64_t* info);
 
 /* _verify_model (src/joint_prediction.py:60-66, 260-274): is the stacked matrix [[C_pp, c0^T], [c0, Sigma]] of the
  * prediction sites of the LAST ck_predict positive definite?  Sigma is (ck_factor succeeded), so this is the
@@ -265,6 +273,12 @@ int ck_debug_mfma_peak(ck_handle* h, int waves_per_simd, int iters, double* out3
  * quantile of the in-kernel shader clock in MHz over the stamped workgroups, their number, a workgroup's median
  * lifetime in shader cycles and in microseconds. */
 int ck_debug_gemm_clock(ck_handle* h, double* out6);
+/* Diagnostic: n_side cooperative panel steps (scratch panel of `rows` rows) on the high-priority side stream against the
+ * first trailing update of the factorisation on the main stream.  mode 0: the update alone, 1: the side kernels alone,
+ * 2: both, released by one event, the first side kernel submitted in front of the update.  out[0] = update ms, out[1 + i] =
+ * end of side kernel i after the common start in ms.  Needs an assembled, unfactored handle of >= 8 panels and destroys
+ * Sigma (assemble again). */
+int ck_debug_stream_overlap(ck_handle* h, int mode, int64_t rows, int n_side, double* out);
 /* Host only (no device needed): the 128 x 128 tiles of one Cholesky trailing update -- block columns J0 + u Jstep, u < nJ,
  * of a matrix whose rows / columns from nvalid on are identity padding -- in the order the launch's workgroups take them
  * (csrc/ck_tilemap.h): out3[3 t .. 3 t + 2] = block column, tile row and tile column inside it, for t < min(total, cap).

@@ -167,6 +167,9 @@ struct ck_handle {
     // look-ahead: the panel step of column K+1 runs on a second (high-priority) stream under the
     // trailing update of panel K
     hipStream_t side = nullptr;
+    hipStream_t side_lo = nullptr;    // a second stream of ordinary priority (option "fused_prio" = 2)
+    int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
+    int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
     // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
@@ -304,6 +307,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     for (auto e : h->ev_col) (void)hipEventDestroy(e);
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side_lo) (void)hipStreamDestroy(h->side_lo);
     if (h->d_coop) (void)hipFree(h->d_coop);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     (void)hipStreamDestroy(h->own_stream);
@@ -1108,6 +1112,92 @@ static int solve_sweep(ck_handle* h) {
         }
     }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Both sweeps AT ONCE (ck_factor_predict): the factorisation on the high-priority side stream, the forward substitution of
+// the right-hand-side rows on the main stream one panel group behind it.  Each sweep alone leaves the chip idle in places
+// the other can fill: the panel chain of the factorisation (one launch, ~0.3 ms per panel, a chain of eight 28 us links
+// that occupies a handful of CUs), the under-filled in-group launches of the substitution (280 tiles for 512 slots), and
+// the drain of every launch (half a tile lifetime on average: ~0.2 ms x 78 launches per sweep).  The sweeps share nothing
+// but the L panels, which the substitution reads a group behind their completion (event per group).  Kernels of two
+// streams do interleave on this chip while a large grid is being dispatched (ck_debug_stream_overlap: dependent
+// side-stream kernels ran, at ~3x their solo latency, under a 32 ms update that they slowed by 1.5 %).
+static int fused_sweeps(ck_handle* h) {
+    if (ensure_events(h)) return -1;
+    if (h->fused_prio == 2 && !h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
+    // option "fused_prio": 0 the factorisation on the high-priority stream | 1 the substitution | 2 neither
+    hipStream_t F = h->fused_prio == 0 ? h->side : h->fused_prio == 1 ? h->stream : h->side_lo;
+    hipStream_t M = h->fused_prio == 1 ? h->side : h->stream;
+    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (F != h->stream) HIPCHK(hipStreamWaitEvent(F, h->ev0, 0));
+    if (M != h->stream) HIPCHK(hipStreamWaitEvent(M, h->ev0, 0));
+    int ge = 0;
+    for (int K0 = 0; K0 < h->nK; K0 += G, ++ge) {
+        const int Gc = std::min(G, h->nK - K0);
+        for (int g = 0; g < Gc; ++g) {
+            if (g > 0) syrk_update(h, F, K0, g, K0 + g, 1, 1);
+            panel_factor_on(h, K0 + g, F);
+        }
+        HIPCHK(hipEventRecord(h->ev_pan[ge], F));   // the group's panels are final
+        if (K0 + Gc < h->nK) syrk_update(h, F, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc);
+        HIPCHK(hipStreamWaitEvent(M, h->ev_pan[ge], 0));
+        for (int g = 0; g < Gc; ++g) {
+            if (g > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend);
+            aux_inner_on(h, K0 + g, h->sig[K0 + g], M);
+        }
+        if (K0 + Gc < h->nK)
+            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend);
+    }
+    HIPCHK(hipEventRecord(h->ev1, F));               // end of the factorisation
+    HIPCHK(hipEventRecord(h->ev2, M));               // end of the substitution
+    if (F != h->stream) HIPCHK(hipStreamWaitEvent(h->stream, h->ev1, 0));
+    if (M != h->stream) HIPCHK(hipStreamWaitEvent(h->stream, h->ev2, 0));
+    HIPCHK(hipEventRecord(h->ev3, h->stream));       // end of both
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ck_assemble_joint must have been called; = ck_factor + ck_predict with the two sweeps overlapped.  *info != 0: Sigma is not
+// positive definite (pred / pred_err untouched), reported exactly as ck_factor reports it.
+extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int64_t m, double* pred, double* pred_err,
+                                 int64_t* info) {
+    CHKH(h);
+    if (h->world != 1) return fail("ck_factor_predict is the single-process form");
+    if (!h->assembled) return fail("ck_assemble_joint has not been called");
+    if (h->factored) return fail("Sigma is already factored; call ck_predict, or ck_assemble_joint again");
+    if (!info) return fail("null info");
+    if (!(h->panel_fused & 2) || h->loo_g0 >= 0) {   // options of the A/B scripts: the plain sequence
+        if (ck_factor(h, info)) return -1;
+        return *info == 0 ? ck_predict(h, i, pcoords, m, pred, pred_err) : 0;
+    }
+    if (ck_aux_begin(h, i, pcoords, m)) return -1;
+    h->gemm_ev_used = 0;
+    if (fused_sweeps(h)) return -1;
+    if (ck_factor_info(h, info)) return -1;
+    unsigned werr = 0;
+    HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+    if (*info != 0 || werr != 0) {
+        // not positive definite, or a cooperative panel step timed out: ck_factor's own handling (redo in the caller's
+        // order for numpy's minor index / without the cooperative step), then the substitution on the finished factor
+        h->assembled = false;
+        h->aux_state = 0;
+        if (ck_assemble_joint(h)) return -1;
+        if (ck_factor(h, info)) return -1;
+        return *info == 0 ? ck_predict(h, i, pcoords, m, pred, pred_err) : 0;
+    }
+    h->factored = true;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->t_ms[1] = ms;    // the factorisation's span (it shares the chip with the substitution)
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev3));
+    h->t_ms[13] = ms;   // both sweeps
+    h->t_ms[3] = h->t_ms[13] - h->t_ms[1];   // what the substitution adds behind the factorisation
+    h->t_ms[12] = 0.0;
+    h->t_ms[5] = h->t_ms[6] = h->t_ms[7] = h->t_ms[8] = 0.0;
+    if (ck_aux_finish(h, pred, pred_err)) return -1;
+    h->aux_state = 2;
     return 0;
 }
 
@@ -2220,6 +2310,60 @@ extern "C" int ck_debug_coop_profile(ck_handle* h, int64_t rows, double* out64) 
     return 0;
 }
 
+// Diagnostic: do small dependent kernels on the high-priority side stream run WHILE a chip-filling trailing update is being
+// dispatched on the main stream, or only after its grid has been placed?  (What a look-ahead of the panel chain under
+// the bulk of the previous group's update needs.)  On an assembled, unfactored handle of >= 8 panels (Sigma is destroyed:
+// assemble again afterwards): mode 0: the update alone | 1: n_side cooperative panel steps on a scratch panel of `rows`
+// rows alone | 2: both -- the first side kernel submitted in front of the update and released by the same event, the others
+// behind it in stream order.  out[0] = update ms (mode 1: 0), out[1 + i] = end of side kernel i after the common start, ms.
+extern "C" int ck_debug_stream_overlap(ck_handle* h, int mode, int64_t rows, int n_side, double* out) {
+    CHKH(h);
+    if (!h->assembled || h->factored || h->nK < 8 || h->world != 1) return fail("needs an assembled, unfactored single-process handle of >= 8 panels");
+    if (!out || rows < CK_NB || rows % 64 || n_side < 0 || n_side > 16 || mode < 0 || mode > 2) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    DevTemps tmp;
+    double* dP = nullptr;
+    long long* dinfo = nullptr;
+    HIPCHK(tmp.get(&dP, (size_t)(rows * CK_NB + CK_PANEL_TAIL) * 8));
+    HIPCHK(tmp.get(&dinfo, 8));
+    std::vector<double> A((size_t)rows * CK_NB);
+    for (int64_t i = 0; i < rows; ++i)
+        for (int j = 0; j < CK_NB; ++j) A[(size_t)i * CK_NB + j] = (i == j ? 600.0 : 0.0) + 1.0 / (1.0 + (double)(i % 977) + j);
+    HIPCHK(hipMemcpyAsync(dP, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(dinfo, 0, 8, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<hipEvent_t> ev(n_side + 2);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    hipStream_t M = h->stream, S = h->side;
+    HIPCHK(hipEventRecord(ev[0], M));
+    if (mode >= 1) {
+        HIPCHK(hipStreamWaitEvent(S, ev[0], 0));
+        for (int i = 0; i < n_side; ++i) {
+            h->coop_seq += 1;
+            ck_launch_panel_coop(S, dP, rows, dP + rows * CK_NB, 0, dinfo, h->d_coop, h->coop_seq, h->d_coop + 16);
+            HIPCHK(hipEventRecord(ev[2 + i], S));
+        }
+    }
+    if (mode != 1) syrk_update(h, M, 0, 3, 3, 1, h->nK - 3);
+    HIPCHK(hipEventRecord(ev[1], M));
+    HIPCHK(hipStreamSynchronize(M));
+    HIPCHK(hipStreamSynchronize(S));
+    HIPCHK(hipGetLastError());
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out[0] = mode != 1 ? ms : 0.0;
+    for (int i = 0; i < n_side; ++i) {
+        out[1 + i] = 0.0;
+        if (mode >= 1) {
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[2 + i]));
+            out[1 + i] = ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    h->assembled = false;
+    return 0;
+}
+
 extern "C" int ck_debug_mfma_probe(ck_handle* h, int32_t* out) {
     CHKH(h);
     int32_t* d = nullptr;
@@ -2362,6 +2506,16 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "time_gemm")) {
         if (value < 0 || value > 2) return fail("time_gemm must be 0, 1 or 2");
         h->time_gemm = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "fused_prio")) {   // see ck_handle::fused_prio
+        if (value < 0 || value > 2) return fail("fused_prio must be 0, 1 or 2");
+        h->fused_prio = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "fused_group")) {
+        if (value < 0 || value > 16) return fail("fused_group must be in [0, 16]");
+        h->fused_group = (int)value;
         return 0;
     }
     if (!strcmp(name, "lookahead")) {   // see ck_handle::lookahead

@@ -101,6 +101,16 @@ class Predictor:
             # scipy.linalg.cho_factor's message (raised uncaught at src/joint_prediction.py:69)
             raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
 
+    @staticmethod
+    def _factor_predict(h, i, pc):
+        """cho_factor + the solve of src/joint_prediction.py:67-78 in one library call: the factorisation and the forward
+        substitution run as two overlapped sweeps (include/cokrige.h: ck_factor_predict); the factor stays resident."""
+        h.assemble_joint()
+        info, pred, err = h.factor_predict(i, pc)
+        if info != 0:
+            raise LinAlgError(f"{info}-th leading minor of the array is not positive definite")
+        return pred, err
+
     def _state_key(self):
         """What the resident factor depends on: the model's parameters, the metric, and the data arrays.  The
         reference re-reads `mod.params` and `mf` on every __call__ (src/joint_prediction.py:50-55); here the factor
@@ -173,14 +183,28 @@ class Predictor:
             self._verdict = None     # the exact _verify_model check is a single-device path: the variance test stands in
             return self._predict_on_ranks(i, pc)
         if cv_ix is None:
-            h = self._factored_handle()
+            key = self._state_key()
+            if self._h is not None and key != self._key:
+                self.invalidate()
+            fresh = self._h is None
+            h = self._new_handle() if fresh else self._h
             # The right-hand sides take (m + 1) x N doubles on the device: very large grids go through the
             # resident factor in batches (one forward sweep each), sized by `rhs_budget_bytes`.
             n_pad = h.num_panels()[2]
             chunk = max(1024, int(self.rhs_budget_bytes // (8 * max(n_pad, 1))))
             self._verdict = None
+            try:
+                if fresh and len(pc) > chunk:
+                    self._factor(h)
+                if len(pc) <= chunk:
+                    # first call on this model and data: factorisation and substitution overlapped
+                    pred, err = self._factor_predict(h, i, pc) if fresh else h.predict(i, pc)
+            except Exception:
+                if fresh:
+                    h.close()
+                raise
+            self._h, self._key = h, key
             if len(pc) <= chunk:
-                pred, err = h.predict(i, pc)
                 self._verdict = self._verify(h, i, pc, err)
             else:
                 parts = [h.predict(i, pc[a:a + chunk]) for a in range(0, len(pc), chunk)]
@@ -190,8 +214,7 @@ class Predictor:
         else:
             h = self._new_handle(drop=(i, cv_ix))
             try:
-                self._factor(h)
-                pred, err = h.predict(i, pc)
+                pred, err = self._factor_predict(h, i, pc)
             finally:
                 h.close()
         return pred, err

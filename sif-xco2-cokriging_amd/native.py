@@ -46,6 +46,7 @@ _PROTOS = {
     "ck_assemble_joint": [c_void_p],
     "ck_factor": [c_void_p, POINTER(c_int64)],
     "ck_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp],
+    "ck_factor_predict": [c_void_p, c_int, _dp, c_int64, _dp, _dp, POINTER(c_int64)],
     "ck_verify_model": [c_void_p, POINTER(c_int64)],
     "ck_loocv": [c_void_p, c_int, _dp, _dp],
     "ck_sample": [c_void_p, _dp, _dp, c_int64],
@@ -77,6 +78,7 @@ _PROTOS = {
     "ck_debug_coop_profile": [c_void_p, c_int64, _dp],
     "ck_debug_mfma_peak": [c_void_p, c_int, c_int, _dp],
     "ck_debug_gemm_clock": [c_void_p, _dp],
+    "ck_debug_stream_overlap": [c_void_p, c_int, c_int64, c_int, _dp],
     "ck_debug_tile_map": [c_int64, c_int, c_int, c_int, POINTER(c_int32), c_int64],
     "ck_debug_run_map": [POINTER(c_int32), c_int, POINTER(c_int32), c_int64],
     "ck_debug_gemm_stamps": [c_void_p, POINTER(c_uint64), c_int64, POINTER(c_int64)],
@@ -322,6 +324,16 @@ class Handle:
         _chk(lib().ck_predict(self._h, int(i), _p(pc), m, _p(pred), _p(err)))
         return pred, err
 
+    def factor_predict(self, i, pcoords):
+        """factor() + predict() with the two sweeps overlapped (include/cokrige.h: ck_factor_predict).  Returns
+        (info, pred, err); info != 0: Sigma is not positive definite, pred / err are meaningless."""
+        pc = _f64(pcoords, 2)
+        m = pc.shape[0]
+        pred, err = np.empty(m), np.empty(m)
+        info = c_int64(0)
+        _chk(lib().ck_factor_predict(self._h, int(i), _p(pc), m, _p(pred), _p(err), byref(info)))
+        return info.value, pred, err
+
     def verify_model(self) -> int:
         """0 if the joint covariance of data and the last predict()'s sites is positive definite, else the index
         of the failing minor (src/joint_prediction.py:260-274; include/cokrige.h: ck_verify_model)."""
@@ -502,6 +514,11 @@ class Handle:
         return dict(mhz_median=out[0], mhz_p05=out[1], mhz_p95=out[2], workgroups=int(out[3]),
                     wg_cycles_median=out[4], wg_us_median=out[5])
 
+    def stream_overlap(self, mode, rows, n_side):
+        out = np.zeros(1 + int(n_side))
+        _chk(lib().ck_debug_stream_overlap(self._h, int(mode), int(rows), int(n_side), _p(out)))
+        return out
+
     def gemm_stamps(self, n_workgroups):
         """Raw workgroup stamps of the last stamped trailing update: (n, 4) uint64 and (grid x, grid y, J0, panels)."""
         out = np.zeros((int(n_workgroups), 4), dtype=np.uint64)
@@ -515,7 +532,7 @@ class Handle:
         _chk(lib().ck_timings(self._h, _p(out), 14))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
                 "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms",
-                "panel_coop_redone", "_unused"]
+                "panel_coop_redone", "fused_sweeps_ms"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):

@@ -578,3 +578,57 @@ def test_postprocess_and_stale_state(native):
     po = orc.Params.from_flat(g["params_A"])
     np.testing.assert_allclose(m0.correlation(0, 1, hlag), orc.matern_correlation(po.nu[0, 1], po.len_scale[0, 1], hlag), rtol=5e-13)
     np.testing.assert_allclose(m0.cross_covariance(0, 1, hlag), 0.0, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["A", "R", "B"])
+def test_factor_predict_overlapped_matches_the_fixture_and_the_sequence(native, tag):
+    """ck_factor_predict (factorisation and substitution as two overlapped sweeps): the reference's fixture at 1e-9, the
+    same bits as ck_factor + ck_predict, and the factor stays resident for further predictions."""
+    g = load_golden("joint_solve")
+    coords = [g[f"coords0_{tag}"], g[f"coords1_{tag}"]]
+    values = [g[f"values0_{tag}"], g[f"values1_{tag}"]]
+    h, p = _assembled(native, g[f"params_{tag}"], coords, values, HAV)
+    info, pred, err = h.factor_predict(0, g[f"pcoords_{tag}"])
+    assert info == 0
+    assert rel(pred, g[f"pred_{tag}_0"]) < 1e-9
+    assert np.max(np.abs(err ** 2 - g[f"pred_err_{tag}_0"] ** 2)) < 1e-10
+    pred1, err1 = h.predict(1, g[f"pcoords_{tag}"])          # on the resident factor
+    assert rel(pred1, g[f"pred_{tag}_1"]) < 1e-9
+    h2, _ = _assembled(native, g[f"params_{tag}"], coords, values, HAV)
+    assert h2.factor() == 0
+    pred2, err2 = h2.predict(0, g[f"pcoords_{tag}"])
+    assert np.array_equal(pred, pred2) and np.array_equal(err, err2)
+    with pytest.raises(native.NativeError):
+        h.factor_predict(0, g[f"pcoords_{tag}"])              # already factored
+
+
+@pytest.mark.parametrize("prio,group", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 4)])
+def test_factor_predict_many_panels_every_schedule(native, prio, group):
+    """Enough panels for groups, look-ahead boundaries and the last, shorter group (N = 5 200: 11 panels); every stream
+    assignment and group size gives the sequence's result."""
+    rng = np.random.default_rng(11)
+    n = 2600
+    coords = [np.column_stack([rng.uniform(25, 49, n), rng.uniform(-124, -67, n)]) for _ in range(2)]
+    values = [rng.standard_normal(n), rng.standard_normal(n)]
+    params = load_golden("joint_solve")["params_A"]
+    pc = np.column_stack([rng.uniform(25, 49, 700), rng.uniform(-124, -67, 700)])
+    h, p = _assembled(native, params, coords, values, HAV)
+    assert h.factor() == 0
+    ref = h.predict(1, pc)
+    h2, _ = _assembled(native, params, coords, values, HAV)
+    h2.set_option("fused_prio", prio)
+    h2.set_option("fused_group", group)
+    info, pred, err = h2.factor_predict(1, pc)
+    assert info == 0
+    tol = 0.0 if group == 0 else 1e-11      # another grouping: another summation order
+    assert rel(pred, ref[0]) <= tol and rel(err, ref[1]) <= tol
+    assert h2.timings()["fused_sweeps_ms"] > 0
+
+
+@pytest.mark.parametrize("site_order", [0, 1])
+def test_factor_predict_not_positive_definite_reports_minor(native, site_order):
+    g = load_golden("joint_not_pd")
+    h, p = _assembled(native, g["params"], [g["coords0"], g["coords1"]], [np.zeros(260), np.zeros(260)], HAV,
+                      site_order=site_order)
+    info, pred, err = h.factor_predict(0, np.array([[35.0, -100.0], [36.0, -101.0]]))
+    assert info == int(g["minor"])
