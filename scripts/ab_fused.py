@@ -16,13 +16,16 @@ for k in range(2):
 pc = pb["pcoords"]
 ref = None
 variants = [("plain", {}), ("fused", {"fused_prio": 0}), ("fusedS", {"fused_prio": 1}), ("fused=", {"fused_prio": 2}),
-            ("fusedG2", {"fused_group": 2}), ("fusedG4", {"fused_group": 4}), ("fusedG6", {"fused_group": 6})]
+            ("fusedG2", {"fused_group": 2}), ("fusedG4", {"fused_group": 4}), ("fusedG6", {"fused_group": 6}),
+            ("fusedLA", {"fused_la": 1}), ("fusedLAG2", {"fused_la": 1, "fused_group": 2}), ("fusedLAG4", {"fused_la": 1, "fused_group": 4}),
+            ("fusedLAG1", {"fused_la": 1, "fused_group": 1})]
 if len(sys.argv) > 3:
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 for it in range(reps):
     for mode, opts in variants:
         h.set_option("fused_prio", 0)
         h.set_option("fused_group", 0)
+        h.set_option("fused_la", 0)
         for k_, v_ in opts.items():
             h.set_option(k_, v_)
         h.assemble_joint()

@@ -170,6 +170,8 @@ struct ck_handle {
     hipStream_t side_lo = nullptr;    // a second stream of ordinary priority (option "fused_prio" = 2)
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
+    int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
+                                      // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
     // option "panel_group": G panels are factored (left-looking inside the group) before the trailing
     // matrix is updated ONCE with K = 512 G (ck_la.hip: gemm_tile_m); 1 = update after every panel
@@ -1159,6 +1161,62 @@ static int fused_sweeps(ck_handle* h) {
     return 0;
 }
 
+// The same with a LOOK-AHEAD inside the factorisation (option "fused_la"): three streams.  C (high priority) carries the
+// critical path -- per panel group g its chain (panel steps and in-group updates) and then A(g), the update of the NEXT
+// group's block columns by group g, which is all the next chain waits for; T carries the bulk of the trailing updates,
+// B1(g) = group g -> block columns of group g + 2 and B2(g) = group g -> everything beyond; the main stream carries the
+// substitution as before.  Every block column still receives its updates in the order of the sequential sweep (group 0,
+// 1, 2, ... each in one launch with K = 512 G), so the factor has the same bits; what changes is that the latency-bound
+// chain of group g + 1 runs UNDER the bulk of group g instead of in front of it.
+//   C:  chain(g) -> [ev_chain g] -> wait B1(g - 1) -> A(g) -> chain(g + 1) ...
+//   T:  wait ev_chain g -> B1(g) -> [ev_B1 g] -> B2(g) -> wait ev_chain g + 1 ...
+//   M:  wait ev_chain g -> substitution of group g
+// (an event is always recorded, in host order, before the wait on it is enqueued: a wait on a never-recorded event is a no-op)
+static int fused_sweeps_la(ck_handle* h) {
+    if (ensure_events(h)) return -1;
+    if (!h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
+    hipStream_t C = h->side, T = h->side_lo, M = h->stream;
+    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    const int ng = (h->nK + G - 1) / G;
+    auto first = [&](int g) { return g * G; };
+    auto count = [&](int g) { return std::min(G, h->nK - g * G); };
+    HIPCHK(hipEventRecord(h->ev0, M));
+    HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
+    HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
+    for (int g = 0; g < ng; ++g) {
+        const int K0 = first(g), Gc = count(g);
+        for (int q = 0; q < Gc; ++q) {
+            if (q > 0) syrk_update(h, C, K0, q, K0 + q, 1, 1);
+            panel_factor_on(h, K0 + q, C);
+        }
+        HIPCHK(hipEventRecord(h->ev_pan[g], C));   // group g's panels are final
+        if (g + 1 < ng) {
+            if (g >= 1) HIPCHK(hipStreamWaitEvent(C, h->ev_col[g - 1], 0));   // B1(g - 1) wrote the same block columns
+            syrk_update(h, C, K0, Gc, first(g + 1), 1, count(g + 1));         // A(g)
+        }
+        HIPCHK(hipStreamWaitEvent(T, h->ev_pan[g], 0));
+        if (g + 2 < ng) {
+            syrk_update(h, T, K0, Gc, first(g + 2), 1, count(g + 2));         // B1(g)
+            HIPCHK(hipEventRecord(h->ev_col[g], T));
+        }
+        if (g + 3 < ng) syrk_update(h, T, K0, Gc, first(g + 3), 1, h->nK - first(g + 3));   // B2(g)
+        HIPCHK(hipStreamWaitEvent(M, h->ev_pan[g], 0));
+        for (int q = 0; q < Gc; ++q) {
+            if (q > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, q, K0 + q, 1, aux_rows(h, K0 + q - 1), h->nend);
+            aux_inner_on(h, K0 + q, h->sig[K0 + q], M);
+        }
+        if (K0 + Gc < h->nK)
+            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend);
+    }
+    HIPCHK(hipEventRecord(h->ev1, C));               // end of the factorisation's chain: the last panel is final
+    HIPCHK(hipEventRecord(h->ev2, T));
+    HIPCHK(hipStreamWaitEvent(M, h->ev1, 0));
+    HIPCHK(hipStreamWaitEvent(M, h->ev2, 0));
+    HIPCHK(hipEventRecord(h->ev3, M));               // end of everything
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ck_assemble_joint must have been called; = ck_factor + ck_predict with the two sweeps overlapped.  *info != 0: Sigma is not
 // positive definite (pred / pred_err untouched), reported exactly as ck_factor reports it.
 extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int64_t m, double* pred, double* pred_err,
@@ -1174,7 +1232,8 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     }
     if (ck_aux_begin(h, i, pcoords, m)) return -1;
     h->gemm_ev_used = 0;
-    if (fused_sweeps(h)) return -1;
+    const bool la = h->fused_la >= 0 ? h->fused_la != 0 : h->nK >= 40;
+    if (la ? fused_sweeps_la(h) : fused_sweeps(h)) return -1;
     if (ck_factor_info(h, info)) return -1;
     unsigned werr = 0;
     HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
@@ -2511,6 +2570,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "fused_prio")) {   // see ck_handle::fused_prio
         if (value < 0 || value > 2) return fail("fused_prio must be 0, 1 or 2");
         h->fused_prio = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "fused_la")) {
+        if (value < -1 || value > 1) return fail("fused_la must be -1 (automatic), 0 or 1");
+        h->fused_la = (int)value;
         return 0;
     }
     if (!strcmp(name, "fused_group")) {
