@@ -25,7 +25,7 @@ for it in range(reps):
     for mode, opts in variants:
         h.set_option("fused_prio", 0)
         h.set_option("fused_group", 0)
-        h.set_option("fused_la", 0)
+        h.set_option("fused_la", 0)   # variants name the look-ahead explicitly
         for k_, v_ in opts.items():
             h.set_option(k_, v_)
         h.assemble_joint()

@@ -602,8 +602,9 @@ def test_factor_predict_overlapped_matches_the_fixture_and_the_sequence(native, 
         h.factor_predict(0, g[f"pcoords_{tag}"])              # already factored
 
 
+@pytest.mark.parametrize("la", [0, 1])
 @pytest.mark.parametrize("prio,group", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 4)])
-def test_factor_predict_many_panels_every_schedule(native, prio, group):
+def test_factor_predict_many_panels_every_schedule(native, prio, group, la):
     """Enough panels for groups, look-ahead boundaries and the last, shorter group (N = 5 200: 11 panels); every stream
     assignment and group size gives the sequence's result."""
     rng = np.random.default_rng(11)
@@ -618,6 +619,7 @@ def test_factor_predict_many_panels_every_schedule(native, prio, group):
     h2, _ = _assembled(native, params, coords, values, HAV)
     h2.set_option("fused_prio", prio)
     h2.set_option("fused_group", group)
+    h2.set_option("fused_la", la)     # three streams: chain + next group's update / bulk / substitution
     info, pred, err = h2.factor_predict(1, pc)
     assert info == 0
     tol = 0.0 if group == 0 else 1e-11      # another grouping: another summation order
