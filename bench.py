@@ -167,6 +167,10 @@ def main():
                          "or 1 (unit square, Euclidean, n_obs = 5000, 100 x 100 grid -- a side measurement)")
     ap.add_argument("--params", default="A")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweeps", default="overlapped", choices=["overlapped", "sequential"],
+                    help="single GPU: the timed step's factorisation and substitution as two overlapped sweeps (ck_factor_predict, "
+                         "the product path, default) or one after the other (ck_factor, ck_predict: what the profiling scripts "
+                         "run, so that a kernel's launches do not share the chip with the other sweep's)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -237,6 +241,8 @@ def main():
             if info != 0:
                 raise RuntimeError(f"Sigma not positive definite at minor {info}")
             return h.predict(0, pb["pcoords"])
+        if args.sweeps == "sequential":
+            step = step_sequential
     else:
         from sif_xco2_cokriging_amd import distributed
         # CK_PANEL_EXCHANGE = broadcast | sag | p2p | auto (default: one mid-size panel through each at warm-up, the
@@ -284,7 +290,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     tim_fused = tim
     seq_ms = None
-    if world == 1:
+    if world == 1 and args.sweeps == "sequential":
+        seq_ms = ms_per_step
+    elif world == 1:
         # per-kernel measurements: sequential passes of the same workload, outside the timed region
         n_seq = max(1, min(args.steps, 3))
         step_sequential()
@@ -366,12 +374,13 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
                 "algorithmic_flops_per_step": flops,
-                "measured_on": (f"{len(tim)} sequential passes of the same workload in this run, behind the timed region (HIP events "
+                "measured_on": "the timed steps (--sweeps sequential)" if args.sweeps == "sequential" else
+                               (f"{len(tim)} sequential passes of the same workload in this run, behind the timed region (HIP events "
                                 "around every launch of the kernel on its stream; ms_per_step of those passes: "
                                 f"{seq_ms:.1f}): in the timed steps the factorisation and the substitution run as two overlapped "
                                 "sweeps on two streams, where a launch's duration includes the other sweep's share of the chip"),
                 # the timed steps themselves: both GEMM kernels (the same gemm_tile_d) against the span of the two sweeps
-                "overlapped": {
+                "overlapped": None if args.sweeps == "sequential" else {
                     "what": "k_syrk_group_d + k_aux_group_d in the timed steps: (N^3/3 + N^2 m) flop / span of the two overlapped sweeps",
                     "sweeps_ms": float(np.mean([t["fused_sweeps_ms"] for t in tim_fused])),
                     "achieved": (trailing_update_flops(N) + aux_update_flops(N, m))
@@ -395,7 +404,8 @@ def main():
                             "definition": "SURVEY 8(d): 8 [N (N + 1) / 2 + N m] algorithmic bytes over K1 + K2"}
             tf = tim_fused[-1]
             out["stages"] = {
-                "timed_steps": {"assemble_sigma_ms": tf["assemble_sigma_ms"], "assemble_c0_ms": tf["assemble_aux_ms"],
+                "timed_steps": None if args.sweeps == "sequential" else
+                               {"assemble_sigma_ms": tf["assemble_sigma_ms"], "assemble_c0_ms": tf["assemble_aux_ms"],
                                 "sweeps_overlapped_ms": tf["fused_sweeps_ms"], "factorisation_span_ms": tf["factor_ms"],
                                 "reduce_ms": tf["reduce_ms"]},
                 "sequential_passes_ms_per_step": seq_ms,

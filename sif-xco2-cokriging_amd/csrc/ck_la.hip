@@ -571,18 +571,12 @@ struct CkSrcSchur {
 };
 
 __global__ __launch_bounds__(512, 4) void k_schur_syrk_d(double* const* __restrict__ schur, const double* __restrict__ aux,
-                                                          long mpad, int np, long Mpad) {
+                                                          long mpad, int np, const CkTileMap map) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
-    const int J = (int)blockIdx.y;
-    const long M = Mpad - (long)J * CK_NB;
-    const int tiles_m = (int)(M / 128), tiles_n = CK_NB / 128;
-    const int nblk = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nblk) return;
-    const int t = xcd_remap(blockIdx.x, nblk);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    int u, tm, tn;   // one workgroup per tile on or below the diagonal, in front of the rows beyond the right-hand-side storage
+    ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
+    const int J = map.J0 + u * map.Jstep;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
-    if (r0 + 127 < c0) return;
-    if ((long)J * CK_NB + r0 + 128 > mpad) return;   // rows beyond the right-hand-side storage: padding, stays identity
     const CkSrcSchur src{aux, mpad, J, r0, c0};
     gemm_tile_d<8>(schur[J], CK_NB, src, np, r0, c0, lds);
 }
@@ -590,8 +584,10 @@ __global__ __launch_bounds__(512, 4) void k_schur_syrk_d(double* const* __restri
 void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,
                           int64_t Mpad) {
     if (nJ <= 0 || np <= 0) return;
-    const dim3 grid((unsigned)((Mpad / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_schur_syrk_d<<<grid, dim3(512), 0, s>>>(schur_dev, aux, mpad, np, Mpad);
+    // rows from floor(mpad / 128) * 128 on are beyond the right-hand-side storage: padding, stays identity
+    const CkTileMap map = ck_tilemap_make(std::min<int64_t>(mpad / 128 * 128, Mpad), 0, 1, nJ);
+    if (map.total <= 0) return;
+    k_schur_syrk_d<<<dim3((unsigned)map.total), dim3(512), 0, s>>>(schur_dev, aux, mpad, np, map);
 }
 
 // srcptr_dev: readable location of every panel (== sigptr_dev in a single-process run); Jstep > 1 is the

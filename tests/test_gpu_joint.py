@@ -634,3 +634,25 @@ def test_factor_predict_not_positive_definite_reports_minor(native, site_order):
                       site_order=site_order)
     info, pred, err = h.factor_predict(0, np.array([[35.0, -100.0], [36.0, -101.0]]))
     assert info == int(g["minor"])
+
+
+@pytest.mark.parametrize("m", [100, 511, 512, 700, 1300])
+def test_verify_model_across_panel_boundaries(native, m):
+    """ck_verify_model's Schur complement (exact launch grid: one workgroup per lower tile in front of the padding) for
+    numbers of prediction sites around the 512-column panel and 256-row alignment boundaries: positive definite for
+    distinct sites of a valid model, as numpy finds the stacked matrix of the oracle."""
+    rng = np.random.default_rng(m)
+    n = 300
+    coords = [np.column_stack([rng.uniform(30, 45, n), rng.uniform(-115, -80, n)]) for _ in range(2)]
+    values = [rng.standard_normal(n), rng.standard_normal(n)]
+    params = load_golden("joint_solve")["params_A"]
+    pc = np.column_stack([rng.uniform(30, 45, m), rng.uniform(-115, -80, m)])
+    h, p = _assembled(native, params, coords, values, HAV)
+    assert h.factor() == 0
+    pred, err = h.predict(0, pc)
+    assert h.verify_model() == 0
+    if m <= 700:   # the reference's own check (src/joint_prediction.py:260-274) on the oracle's matrices
+        S = orc.joint_cov(p, coords, HAV)
+        c0 = orc.pred_cross_cov(p, coords, pc, 0, HAV)
+        cpp = orc.pred_cov(p, pc, 0, HAV)
+        np.linalg.cholesky(np.block([[cpp, c0.T], [c0, S]]))
