@@ -29,6 +29,9 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
 st = glob.glob(f"{G}/prof_{tag}/trace/**/*kernel_stats.csv", recursive=True)
 if st:
     cp(st[0], f"{tag}_bench_n20k_kernel_stats.csv")
+so = glob.glob(f"{G}/prof_{tag}/trace_overlapped/**/*kernel_stats.csv", recursive=True)
+if so:
+    cp(so[0], f"{tag}_trace_overlapped_kernel_stats.csv")   # the default (overlapped) form of the same command
 cp(f"{G}/prof_{tag}_bench_line.json", f"{tag}_bench_n20k.json")
 cp(f"{G}/prof_{tag}_bench_config1.json", f"{tag}_bench_config1_n5k.json")
 cp(f"{G}/prof_{tag}_bench_n50k.json", f"{tag}_bench_n50k_1gpu.json")
