@@ -12,7 +12,7 @@ ntrial = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 worst = 0.0
 for trial in range(ntrial):
     metric = int(rng.integers(0, 2))
-    n0 = int(rng.choice([1, 17, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1025, 1400]))
+    n0 = int(rng.choice([1, 17, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1025, 1400, 2300]))
     n1 = int(rng.choice([1, 30, 64, 200, 448, 449, 512, 600, 1100]))
     uni = rng.random() < 0.2
     if metric == 0:
@@ -44,8 +44,16 @@ for trial in range(ntrial):
     for k in range(len(coords)):
         h.set_data(k, coords[k], values[k])
     h.assemble_joint()
-    info = h.factor()
     i = 0 if uni else int(rng.integers(0, 2))
+    fused = rng.random() < 0.6    # ck_factor_predict: the two sweeps overlapped, random stream assignment / grouping / look-ahead
+    if fused:
+        fo = {"fused_prio": int(rng.integers(0, 3)), "fused_group": int(rng.integers(0, 5)), "fused_la": int(rng.integers(-1, 2))}
+        for k, v in fo.items():
+            h.set_option(k, v)
+        opts.update(fo)
+        info, pred, err = h.factor_predict(i, pc)
+    else:
+        info = h.factor()
     try:
         rp, re = orc.joint_predict(op, coords, values, pc, i, metric)
     except np.linalg.LinAlgError:
@@ -54,7 +62,8 @@ for trial in range(ntrial):
         h.close()
         continue
     assert info == 0, info
-    pred, err = h.predict(i, pc)
+    if not fused:
+        pred, err = h.predict(i, pc)
     dev = max(float(np.max(np.abs(pred - rp)) / max(1.0, float(np.max(np.abs(rp))))), float(np.max(np.abs(err ** 2 - re ** 2))))
     ni = len(coords[i])
     if ni >= 3:
