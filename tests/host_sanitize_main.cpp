@@ -78,6 +78,38 @@ int main() {
         }
         CHECK(ck_ref_distance(7, A.data(), B.data(), n, out.data()) != 0);
     }
+    // ---- workgroup -> tile maps (ck_tilemap.h) ------------------------------------------------------------------------
+    for (int64_t nvalid : {(int64_t)1, (int64_t)129, (int64_t)513, (int64_t)4600, (int64_t)40000, (int64_t)100096}) {
+        const int nK = (int)((nvalid + 511) / 512);
+        for (int J0 : {0, nK / 2, nK - 1})
+            for (int Jstep : {1, 3}) {
+                const int nJ = (nK - 1 - J0) / Jstep + 1;
+                const int64_t total = ck_debug_tile_map(nvalid, J0, Jstep, nJ, nullptr, 0);
+                CHECK(total >= 1);
+                std::vector<int32_t> out((size_t)(3 * total));
+                CHECK(ck_debug_tile_map(nvalid, J0, Jstep, nJ, out.data(), total) == total);
+                for (int64_t t = 0; t < total; ++t) {
+                    CHECK(out[(size_t)(3 * t)] >= J0 && out[(size_t)(3 * t)] < nK);
+                    CHECK(out[(size_t)(3 * t + 2)] >= 0 && out[(size_t)(3 * t + 2)] <= 3 && out[(size_t)(3 * t + 2)] <= out[(size_t)(3 * t + 1)]);
+                }
+            }
+    }
+    CHECK(ck_debug_tile_map(1000, 2, 1, 1, nullptr, 0) < 0);
+    {
+        std::vector<int32_t> counts;
+        for (int y = 0; y < 5000; ++y) counts.push_back((int32_t)((5000 - y) / 37));
+        const int64_t total = ck_debug_run_map(counts.data(), (int)counts.size(), nullptr, 0);
+        CHECK(total > 0);
+        std::vector<int32_t> out((size_t)(2 * total));
+        CHECK(ck_debug_run_map(counts.data(), (int)counts.size(), out.data(), total) == total);
+        int64_t real = 0, want = 0;
+        for (int64_t b = 0; b < total; ++b)
+            if (out[(size_t)(2 * b)] >= 0 && out[(size_t)(2 * b + 1)] < counts[(size_t)out[(size_t)(2 * b)]]) ++real;
+        for (int32_t c : counts) want += c;
+        CHECK(real == want);
+        counts[10] = counts[9] + 1;
+        CHECK(ck_debug_run_map(counts.data(), (int)counts.size(), nullptr, 0) < 0);
+    }
     // ---- variogram levels, clusters, tie decisions ------------------------------------------------------------------
     for (int metric = 0; metric < 2; ++metric) {
         const int nb = 30;
