@@ -300,7 +300,9 @@ int ck_debug_gemm_stamps(ck_handle* h, uint64_t* out_host, int64_t n_words, int6
  * trailing updates of the last ck_predict; [9] variogram binning pass (ck_vario_bin); [10] local prediction kernels (ck_predict_local);
  * [11] ck_verify_model (host wall clock, synchronised); [12] 1 if the last ck_factor had to repeat the factorisation because
  * a workgroup of the cooperative panel step (option "panel_fused" bit 4) timed out waiting for a pivot block (never
- * observed; the bit is then off for the handle). */
+ * observed; the bit is then off for the handle); [13] after ck_factor_predict: the span of the two overlapped sweeps -- [1] is then the
+ * factorisation's span inside it (it shares the chip with the substitution), [3] what the substitution adds behind the
+ * factorisation's end, and [5] .. [8] are 0 (a launch's duration would include the other sweep's share of the chip). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it
