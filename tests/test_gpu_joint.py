@@ -656,3 +656,27 @@ def test_verify_model_across_panel_boundaries(native, m):
         c0 = orc.pred_cross_cov(p, coords, pc, 0, HAV)
         cpp = orc.pred_cov(p, pc, 0, HAV)
         np.linalg.cholesky(np.block([[cpp, c0.T], [c0, S]]))
+
+
+def test_factor_predict_zero_and_one_point_and_univariate(native):
+    """Edge shapes of the overlapped form: no prediction site, one site, a univariate model, a single tiny panel."""
+    g = load_golden("joint_loocv")
+    coords, values = [g["coords0"], g["coords1"]], [g["values0"], g["values1"]]
+    h, p = _assembled(native, g["params"], coords, values, HAV)
+    info, pred, err = h.factor_predict(0, np.zeros((0, 2)))
+    assert info == 0 and pred.shape == (0,) and err.shape == (0,)
+    one = np.array([[38.0, -95.0]])
+    p1, e1 = h.predict(1, one)                               # on the factor the empty call left resident
+    h2, _ = _assembled(native, g["params"], coords, values, HAV)
+    info, p2, e2 = h2.factor_predict(1, one)
+    assert info == 0 and np.array_equal(p1, p2) and np.array_equal(e1, e2)
+    rp, re = orc.joint_predict(p, coords, values, one, 1, HAV)
+    assert rel(p2, rp) < 1e-9 and abs(e2[0] - re[0]) < 1e-9
+    k = load_golden("kat_simulation_experiment")
+    hu, pu = _assembled(native, k["params_uni"], [k["coords1"]], [k["values1"]], EUC)
+    info, pred, err = hu.factor_predict(0, k["pcoords"])
+    assert info == 0 and rel(pred, k["pred_uni"]) < 1e-6 and np.max(np.abs(err - k["pred_err_uni"])) < 1e-6
+    ht, pt = _assembled(native, g["params"], [coords[0][:3], coords[1][:2]], [values[0][:3], values[1][:2]], HAV)
+    info, pred, err = ht.factor_predict(0, one)
+    rp, re = orc.joint_predict(pt, [coords[0][:3], coords[1][:2]], [values[0][:3], values[1][:2]], one, 0, HAV)
+    assert info == 0 and rel(pred, rp) < 1e-9 and abs(err[0] - re[0]) < 1e-9
