@@ -23,7 +23,8 @@ def run():
     for k in range(2):
         h.set_data(k, pb["coords"][k], pb["values"][k])
     lap("set_data")
-    h.assemble_joint(); lap("assemble_joint (layout, allocation, tables, K1)")
+    h.num_panels(); lap("layout (Hilbert sort, uploads, allocation, tables)")
+    h.assemble_joint(); lap(f"assemble_joint (K1 on fresh memory: {h.timings()['assemble_sigma_ms']:.2f} ms by events)")
     info, pred, err = h.factor_predict(0, pb["pcoords"]); lap("factor_predict (aux allocation, K2, sweeps, reduce, results)")
     tm = h.timings()
     h.close(); lap("close")

@@ -525,9 +525,19 @@ static int ensure_layout(ck_handle* h) {
     // panels
     if (h->sig.empty()) {
         h->sig.assign(h->nK, nullptr);
+        // the owned panels from ONE allocation (outside a caller's arena, where dev_alloc carves anyway): 79 hipMalloc /
+        // hipFree calls of tens of MB each were most of what a cold pass spent in its first assemble and in ck_destroy
+        // beyond the kernels (scripts/diag_cold_phases.py)
+        auto panel_bytes = [&](int K) {
+            return (((Np - (int64_t)K * CK_NB) * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES + 255) & ~(int64_t)255;
+        };
+        int64_t slab_bytes = 0;
+        for (int K = h->rank; K < h->nK; K += h->world) slab_bytes += panel_bytes(K);
+        char* slab = nullptr;
+        if (dev_alloc(h, (void**)&slab, slab_bytes)) return -1;
         for (int K = h->rank; K < h->nK; K += h->world) {
-            const int64_t rows = Np - (int64_t)K * CK_NB;
-            if (dev_alloc(h, (void**)&h->sig[K], (rows * CK_NB + CK_PANEL_TAIL) * 8 + CK_PANEL_SLACK_BYTES)) return -1;
+            h->sig[K] = (double*)slab;
+            slab += panel_bytes(K);
         }
         if (dev_alloc(h, (void**)&h->d_sigptr, (int64_t)h->nK * sizeof(double*))) return -1;
         HIPCHK(hipMemcpy(h->d_sigptr, h->sig.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
