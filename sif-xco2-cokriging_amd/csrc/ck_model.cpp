@@ -159,10 +159,12 @@ extern "C" int ck_table_plan(const CkMatern* m, int metric, double qbox_euclid, 
     if (top - base > CK_TAB_MAXINT) base = top - CK_TAB_MAXINT;
     const int n_int = (int)(top - base);
     if (n_int <= 0) return 0;
+    long double node[CK_ND];   // the same eight node positions in every interval (cosl once, not once per node and interval)
+    for (int j = 0; j < CK_ND; ++j) node[j] = cheb_node(j);
     for (int it = 0; it < n_int; ++it) {
         const long double qa = ck_table_edge(base + it), qb = ck_table_edge(base + it + 1);
         for (int j = 0; j < CK_ND; ++j)
-            q_nodes[it * CK_ND + j] = (double)(qa + (cheb_node(j) + 1.0L) * 0.5L * (qb - qa));
+            q_nodes[it * CK_ND + j] = (double)(qa + (node[j] + 1.0L) * 0.5L * (qb - qa));
     }
     *base_out = base;
     return n_int;
@@ -182,12 +184,17 @@ extern "C" void ck_table_fit(const double* f, int n_int, int64_t base, double* c
     Tm[1][1] = 1;
     for (int k = 2; k < CK_ND; ++k)
         for (int i = 0; i < CK_ND; ++i) Tm[k][i] = (i > 0 ? 2 * Tm[k - 1][i - 1] : 0) - Tm[k - 2][i];
+    // the cosines of the discrete Chebyshev transform are the same for every interval: 64 cosl calls here instead of 64 per
+    // interval (3 blocks x ~700 intervals of them were 15 ms of a handle's first assemble); same values, same coefficients
+    long double cs[CK_ND][CK_ND];
+    for (int k = 0; k < CK_ND; ++k)
+        for (int j = 0; j < CK_ND; ++j) cs[k][j] = cosl(PI * k * (j + 0.5L) / CK_ND);
     for (size_t i = 0; i < (size_t)CK_ND * CK_TAB_STRIDE; ++i) coef_kmajor[i] = 0.0;
     for (int it = 0; it < n_int; ++it) {
         long double ck[CK_ND];
         for (int k = 0; k < CK_ND; ++k) {
             long double acc = 0;
-            for (int j = 0; j < CK_ND; ++j) acc += (long double)f[it * CK_ND + j] * cosl(PI * k * (j + 0.5L) / CK_ND);
+            for (int j = 0; j < CK_ND; ++j) acc += (long double)f[it * CK_ND + j] * cs[k][j];
             ck[k] = acc * (k == 0 ? 1.0L : 2.0L) / CK_ND;
         }
         const long double scale = 2.0L / ((long double)ck_table_edge(base + it + 1) - (long double)ck_table_edge(base + it));
