@@ -462,8 +462,11 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         CK_DMA_CHUNK((stage_), (long)kc * (GEMM_BK * 8));     \
     }
     if (nst > 1) CK_DMA_NEXT(1);     // chunk 1 (chunk 0 has landed: waited for above)
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
+    // The loop runs two chunks per iteration (the number of chunks is a multiple of 32), so that the LDS stage of a chunk
+    // is a compile-time constant: the fragment reads take it as the immediate offset of ds_read_b128 instead of six vector
+    // instructions per chunk that add it to the per-lane addresses.
+    auto step = [&](auto cur_c, int st) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_c)::value;
         const char* sb = lds + cur * STAGE;
         d2_t af[2][4], bf[2][WJ];
 #pragma unroll
@@ -494,6 +497,10 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i][h], bf[1][j][h], acc[i][j], 0, 0, 0);
+    };
+    for (int st = 0; st < nst; st += 2) {
+        step(std::integral_constant<int, 0>{}, st);
+        step(std::integral_constant<int, 1>{}, st + 1);
     }
 #undef CK_DMA_NEXT
 #undef CK_DMA_CHUNK
