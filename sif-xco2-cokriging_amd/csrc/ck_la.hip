@@ -213,21 +213,33 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
     constexpr int BOFF = 128 * 128;              // B rows follow the 128 A rows
     constexpr int STAGE = 256 * 128;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int li = lane & 15, g = lane >> 4;
     const long wr = r0 + wm * 64, wc = c0 + wn * 32;
-    const bool active = !CLIP || (wr < row_lim && wc < col_lim && !(lower && wc > wr + 63));
+    const bool active = !CLIP || (wr < row_lim && wc < col_lim && !(lower && wc > wr + 63));   // wave-uniform (scalar)
 
-    const ck_gchar* Ab = as_global(reinterpret_cast<const char*>(A + r0 * lda));
-    const ck_gchar* Bb = as_global(reinterpret_cast<const char*>(B + c0 * ldb));
     ck_gdouble* Cb = (ck_gdouble*)as_global(reinterpret_cast<char*>(C + r0 * ldc + c0));
+    // Operand loads as buffer_load_dwordx4: the tile's A / B rows in a resource descriptor (scalar), one 32-bit offset
+    // register per load (constant over the K loop), the chunk's byte offset as the scalar offset -- like the DMA tile, no
+    // vector instruction in the MFMA loop that is not a load, a fragment read or an LDS write: the sign of A moved into the
+    // accumulators (they start as -C and are stored as -acc), the LDS stage is a compile-time constant (two chunks per
+    // iteration).  Rounds 1-3 had, per chunk and wave, four 64-bit address adds, six LDS address adds and eight
+    // instructions for the negation in this loop; in gemm_tile_d the ten of them cost 4 % of the kernel.
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(A + r0 * lda), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(B + c0 * ldb), (short)0, 0x7fffffff, 0x00020000);
     // staging: chunk (row = tid >> 3 (+64 u), pair p = tid & 7) -> slot p ^ ((row >> 1) & 7); row + 64 u keeps the swizzle
     const int srow = tid >> 3, sp = tid & 7;
-    const unsigned a_src0 = (unsigned)(srow * (int)lda + sp * 2) * 8u;
-    const unsigned b_src0 = (unsigned)(srow * (int)ldb + sp * 2) * 8u;
+    unsigned a_off[2], b_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        a_off[u] = (unsigned)((srow + 64 * u) * (int)lda + sp * 2) * 8u;
+        b_off[u] = (unsigned)((srow + 64 * u) * (int)ldb + sp * 2) * 8u;
+    }
     const int s_dst0 = srow * 128 + ((sp ^ ((srow >> 1) & 7)) << 4);
-    const long a_step = 64 * lda * 8, b_step = 64 * ldb * 8;   // bytes, wave-uniform
     const unsigned c_off = (unsigned)((wm * 64 + g) * (int)ldc + wn * 32 + li) * 8u;
     int a_rd[2], b_rd[2];
 #pragma unroll
@@ -236,12 +248,12 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
         a_rd[kb] = (wm * 64 + li) * 128 + slot * 16;
         b_rd[kb] = BOFF + (wn * 32 + li) * 128 + slot * 16;
     }
-
-    d2_t ra[2], rb[2];
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t ra[2], rb[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + u * a_step + a_src0);
-        rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + u * b_step + b_src0);
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_off[u], 0, 0);
+        rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[u], 0, 0);
     }
     d4_t acc[4][2];
     if (active) {
@@ -251,55 +263,63 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
             for (int r = 0; r < 4; ++r) {
                 const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j][r] = *reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
+                for (int j = 0; j < 2; ++j) acc[i][j][r] = -*reinterpret_cast<const ck_gdouble*>(rowp + j * 128 + c_off);
             }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        *reinterpret_cast<d2_t*>(lds + s_dst0 + u * 8192) = -ra[u];
-        *reinterpret_cast<d2_t*>(lds + BOFF + s_dst0 + u * 8192) = rb[u];
+        *reinterpret_cast<v4u_t*>(lds + s_dst0 + u * 8192) = ra[u];
+        *reinterpret_cast<v4u_t*>(lds + BOFF + s_dst0 + u * 8192) = rb[u];
     }
     __builtin_amdgcn_s_waitcnt(0);   // C loads drained here, not inside the loop (see gemm_tile)
     __syncthreads();
 
     const int nst = K / GEMM_BK;
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
+    auto step = [&](auto cur_c, int st) __attribute__((always_inline)) {
+        constexpr int cur = decltype(cur_c)::value;
         const bool more = (st + 1 < nst);
         if (more) {
-            const long k0 = (long)(st + 1) * (GEMM_BK * 8);
+            const int kb_ = (st + 1) * (GEMM_BK * 8);   // byte offset of the next chunk inside a row
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                ra[u] = *reinterpret_cast<const ck_gd2*>(Ab + (k0 + u * a_step) + a_src0);
-                rb[u] = *reinterpret_cast<const ck_gd2*>(Bb + (k0 + u * b_step) + b_src0);
+                ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_off[u], kb_, 0);
+                rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)b_off[u], kb_, 0);
             }
         }
         const char* sb = lds + cur * STAGE;
+        if (active) {
 #pragma unroll
-        for (int kb = 0; kb < 2 && active; ++kb) {
-            d2_t af[4], bf[2];
+            for (int kb = 0; kb < 2; ++kb) {
+                d2_t af[4], bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][h], bf[j][h], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) {
             char* nx = lds + (cur ^ 1) * STAGE;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                *reinterpret_cast<d2_t*>(nx + s_dst0 + u * 8192) = -ra[u];
-                *reinterpret_cast<d2_t*>(nx + BOFF + s_dst0 + u * 8192) = rb[u];
+                *reinterpret_cast<v4u_t*>(nx + s_dst0 + u * 8192) = ra[u];
+                *reinterpret_cast<v4u_t*>(nx + BOFF + s_dst0 + u * 8192) = rb[u];
             }
         }
         __syncthreads();
+    };
+    int st = 0;
+    for (; st + 1 < nst; st += 2) {
+        step(std::integral_constant<int, 0>{}, st);
+        step(std::integral_constant<int, 1>{}, st + 1);
     }
+    if (st < nst) step(std::integral_constant<int, 0>{}, st);
     // The 16 row addresses are recomputed here from a laundered copy of the (wave-uniform) tile pointer: left to
     // itself hipcc keeps the prologue's sixteen 64-bit row pointers alive in VGPRs across the K loop for reuse
     // and, at the 128-VGPR budget of four waves per SIMD, spills them (22 VGPRs of scratch before this).
@@ -312,7 +332,7 @@ __device__ __forceinline__ void gemm_tile_e(double* __restrict__ C, long ldc, co
         for (int r = 0; r < 4; ++r) {
             ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Ce + (long)(i * 16 + 4 * r) * ldc);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = acc[i][j][r];
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<ck_gdouble*>(rowp + j * 128 + c_off) = -acc[i][j][r];
         }
 }
 
