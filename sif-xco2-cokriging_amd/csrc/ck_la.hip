@@ -1025,42 +1025,59 @@ __device__ __forceinline__ double ld_shared_result(const double* p) {
     return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
+// Staging (round 3, second session): the slabs arrive through buffer_load_dwordx4 -- the chunk's / the pivot's rows in a
+// resource descriptor, ONE per-lane offset register (row tid >> 5 of eight, column pair tid & 31), the slab's and the row
+// group's byte offset as the scalar offset (scalar adds) -- and go to LDS with ds_write_b128; the sign of A sits in the
+// accumulators (-C in, negated once at the end).  Before, every one of a slab's 32 eight-byte loads per thread had its own
+// 64-bit address arithmetic and every A element its own negation: ~110 vector instructions per slab and wave beside 64
+// MFMAs (device assembly), and a plain vector instruction in an MFMA loop costs far more than its issue slot (gemm_tile_d).
 template <bool SOLVE, bool COH = false, bool PUB = false>
 __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const double* __restrict__ Ar, long ld,
                                              const double* __restrict__ Br, long ldb, int i,
                                              const double* __restrict__ Linv, double* As, double* Bs) {
+    static_assert(!COH, "the coherent variant lives in k_panel_coop's own body");
     constexpr int PITCH = 66;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int sr = tid >> 6, sc = tid & 63;   // staging: element (sr + 4 u, sc), u < 16
-    double ra[16], rb[16];
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = tid >> 5, scp = tid & 31;   // staging: elements (srow + 8 u, 2 scp .. 2 scp + 1), u < 8
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ar, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Br, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)Linv, (short)0, 0x7fffffff, 0x00020000);
+    const int a_vo = (srow * (int)ld + 2 * scp) * 8, b_vo = (srow * (int)ldb + 2 * scp) * 8, l_vo = (srow * 64 + 2 * scp) * 8;
+    const int a_rs = 8 * (int)ld * 8, b_rs = 8 * (int)ldb * 8;   // byte stride of a group of eight rows
+    double* const As_w = As + srow * PITCH + 2 * scp;
+    double* const Bs_w = Bs + srow * PITCH + 2 * scp;
+    v4u_t ra[8], rb[8];
     if (i > 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            ra[u] = Ar[(long)(sr + 4 * u) * ld + sc];
-            rb[u] = ld_shared_result<COH>(Br + (long)(sr + 4 * u) * ldb + sc);
+        for (int u = 0; u < 8; ++u) {
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_vo, u * a_rs, 0);
+            rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_vo, u * b_rs, 0);
         }
     }
-    d4_t cn[4];
+    d4_t cn[4];   // = -(C - sum A B^T): the accumulators carry the sign, A goes to LDS as it is
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cn[jt][r] = C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li];
+        for (int r = 0; r < 4; ++r) cn[jt][r] = -C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li];
     for (int ks = 0; ks < i; ++ks) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            As[(sr + 4 * u) * PITCH + sc] = -ra[u];
-            Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+        for (int u = 0; u < 8; ++u) {
+            *reinterpret_cast<v4u_t*>(As_w + 8 * u * PITCH) = ra[u];
+            *reinterpret_cast<v4u_t*>(Bs_w + 8 * u * PITCH) = rb[u];
         }
         __syncthreads();
         if (ks + 1 < i) {
+            const int so = 64 * (ks + 1) * 8;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                ra[u] = Ar[(long)(sr + 4 * u) * ld + 64 * (ks + 1) + sc];
-                rb[u] = ld_shared_result<COH>(Br + (long)(sr + 4 * u) * ldb + 64 * (ks + 1) + sc);
+            for (int u = 0; u < 8; ++u) {
+                ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_vo, so + u * a_rs, 0);
+                rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_vo, so + u * b_rs, 0);
             }
         } else if (SOLVE) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) rb[u] = ld_shared_result<COH>(Linv + (sr + 4 * u) * 64 + sc);
+            for (int u = 0; u < 8; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsL, l_vo, u * (8 * 64 * 8), 0);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
@@ -1075,20 +1092,21 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = cn[jt][r];
+            for (int r = 0; r < 4; ++r) C[(long)(16 * w + g + 4 * r) * ld + 16 * jt + li] = -cn[jt][r];
         return;
     }
     if (i == 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) rb[u] = ld_shared_result<COH>(Linv + (sr + 4 * u) * 64 + sc);
+        for (int u = 0; u < 8; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsL, l_vo, u * (8 * 64 * 8), 0);
     }
-    // the updated chunk becomes the A operand (each wave re-reads only the 16 rows it wrote), Linv the B operand
+    // the updated chunk (still negated) becomes the A operand (each wave re-reads only the 16 rows it wrote), Linv the B
+    // operand; the product's sign is turned back in front of the store
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) As[(16 * w + g + 4 * r) * PITCH + 16 * jt + li] = cn[jt][r];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<v4u_t*>(Bs_w + 8 * u * PITCH) = rb[u];
     __syncthreads();
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -1098,7 +1116,7 @@ __device__ __forceinline__ void lt_rows_body(double* __restrict__ C, const doubl
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * w + li) * PITCH + 4 * s2 + g],
                                                       Bs[(16 * jt + li) * PITCH + 4 * s2 + g], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st_shared_result<PUB>(C + (long)(16 * w + g + 4 * r) * ld + 16 * jt + li, acc[r]);
+        for (int r = 0; r < 4; ++r) st_shared_result<PUB>(C + (long)(16 * w + g + 4 * r) * ld + 16 * jt + li, -acc[r]);
     }
 }
 
