@@ -127,7 +127,7 @@ def measured_traffic():
     runs of this very command, KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
     streams).  A committed measurement of the same workload, NOT a live counter of this run -- `traffic_source` in the
     bench line says which file it came from; (None, None) if absent."""
-    for name in ("r03b_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -380,7 +380,7 @@ def main():
                                 f"{seq_ms:.1f}): in the timed steps the factorisation and the substitution run as two overlapped "
                                 "sweeps on two streams, where a launch's duration includes the other sweep's share of the chip"),
                 # the timed steps themselves: both GEMM kernels (the same gemm_tile_d) against the span of the two sweeps
-                "overlapped": None if args.sweeps == "sequential" else {
+                "overlapped": None if (args.sweeps == "sequential" or tim_fused[-1]["fused_sweeps_ms"] <= 0) else {
                     "what": "k_syrk_group_d + k_aux_group_d in the timed steps: (N^3/3 + N^2 m) flop / span of the two overlapped sweeps",
                     "sweeps_ms": float(np.mean([t["fused_sweeps_ms"] for t in tim_fused])),
                     "achieved": (trailing_update_flops(N) + aux_update_flops(N, m))
@@ -406,7 +406,10 @@ def main():
             out["stages"] = {
                 "timed_steps": None if args.sweeps == "sequential" else
                                {"assemble_sigma_ms": tf["assemble_sigma_ms"], "assemble_c0_ms": tf["assemble_aux_ms"],
-                                "sweeps_overlapped_ms": tf["fused_sweeps_ms"], "factorisation_span_ms": tf["factor_ms"],
+                                "sweeps_overlapped_ms": tf["fused_sweeps_ms"] if tf["fused_sweeps_ms"] > 0 else None,
+                                "sweeps": "overlapped (ck_factor_predict)" if tf["fused_sweeps_ms"] > 0 else
+                                          "sequential inside ck_factor_predict (more than 128 panels: the library's automatic rule)",
+                                "factorisation_span_ms": tf["factor_ms"],
                                 "reduce_ms": tf["reduce_ms"]},
                 "sequential_passes_ms_per_step": seq_ms,
                 "note": "the entries below are from the sequential passes (ck_factor, then ck_predict)",

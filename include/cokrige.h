@@ -122,7 +122,9 @@ int ck_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, doubl
  * src/joint_prediction.py:60-78, does exactly this sequence): the factorisation and the forward substitution of the
  * right-hand sides run as two overlapped sweeps, the substitution one panel group behind the factorisation, so that each
  * fills the other's idle stretches (panel chain, under-filled in-group launches, launch drains).  Same results to rounding,
- * same *info and error behaviour as ck_factor; *info != 0 leaves pred / pred_err untouched.  The factor stays resident:
+ * same *info and error behaviour as ck_factor; *info != 0 leaves pred / pred_err untouched.  Beyond 128 panels (N > 65 536),
+ * where the overlap no longer pays, the call runs the two sweeps one after the other (option "fused_sweeps": -1 this rule,
+ * 0 never overlapped, 1 always).  The factor stays resident:
  * further ck_predict calls work as after ck_factor. */
 int ck_factor_predict(ck_handle* h, int i, const double* pcoords_host, int64_t m, double* pred_host, double* pred_err_host,
                       int64_t* info);

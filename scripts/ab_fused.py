@@ -23,6 +23,7 @@ if len(sys.argv) > 3:
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 for it in range(reps):
     for mode, opts in variants:
+        h.set_option("fused_sweeps", 1)   # overlapped whatever the size (the automatic rule stops at 128 panels)
         h.set_option("fused_prio", 0)
         h.set_option("fused_group", 0)
         h.set_option("fused_la", 0)   # variants name the look-ahead explicitly

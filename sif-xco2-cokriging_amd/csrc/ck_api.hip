@@ -168,6 +168,7 @@ struct ck_handle {
     // trailing update of panel K
     hipStream_t side = nullptr;
     hipStream_t side_lo = nullptr;    // a second stream of ordinary priority (option "fused_prio" = 2)
+    int fused_sweeps_opt = -1;        // ck_factor_predict: -1 automatic (overlapped up to 128 panels) | 0 sequential | 1 overlapped
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
@@ -1236,7 +1237,13 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     if (!h->assembled) return fail("ck_assemble_joint has not been called");
     if (h->factored) return fail("Sigma is already factored; call ck_predict, or ck_assemble_joint again");
     if (!info) return fail("null info");
-    if (!(h->panel_fused & 2) || h->loo_g0 >= 0) {   // options of the A/B scripts: the plain sequence
+    // Overlapping pays while a sweep leaves the chip EMPTY for a noticeable share of its time (panel chain, launch drains):
+    // 15-20 % at 20 panels, 2-4 % at 79, and at 196 panels (N = 100 000) between +1.5 % and -2 % depending on the device --
+    // the launches are long against their drains there, and two kernels sharing the chip cost each other efficiency.
+    // Automatic rule (option "fused_sweeps" = -1): overlapped up to 128 panels, one sweep after the other beyond.
+    const bool overlap = h->fused_sweeps_opt >= 0 ? h->fused_sweeps_opt != 0 : h->nK <= 128;
+    if (!(h->panel_fused & 2) || h->loo_g0 >= 0 || !overlap) {   // (also: options of the A/B scripts) the plain sequence
+        h->t_ms[13] = 0.0;   // no overlapped span: ck_timings [1] and [3] are the two sweeps' own times
         if (ck_factor(h, info)) return -1;
         return *info == 0 ? ck_predict(h, i, pcoords, m, pred, pred_err) : 0;
     }
@@ -2575,6 +2582,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "time_gemm")) {
         if (value < 0 || value > 2) return fail("time_gemm must be 0, 1 or 2");
         h->time_gemm = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "fused_sweeps")) {
+        if (value < -1 || value > 1) return fail("fused_sweeps must be -1 (automatic), 0 or 1");
+        h->fused_sweeps_opt = (int)value;
         return 0;
     }
     if (!strcmp(name, "fused_prio")) {   // see ck_handle::fused_prio

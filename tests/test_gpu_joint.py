@@ -670,6 +670,10 @@ def test_factor_predict_zero_and_one_point_and_univariate(native):
     h2, _ = _assembled(native, g["params"], coords, values, HAV)
     info, p2, e2 = h2.factor_predict(1, one)
     assert info == 0 and np.array_equal(p1, p2) and np.array_equal(e1, e2)
+    h3, _ = _assembled(native, g["params"], coords, values, HAV)
+    h3.set_option("fused_sweeps", 0)                         # the call's sequential form (automatic beyond 128 panels)
+    info, p3, e3 = h3.factor_predict(1, one)
+    assert info == 0 and np.array_equal(p1, p3) and np.array_equal(e1, e3) and h3.timings()["fused_sweeps_ms"] == 0
     rp, re = orc.joint_predict(p, coords, values, one, 1, HAV)
     assert rel(p2, rp) < 1e-9 and abs(e2[0] - re[0]) < 1e-9
     k = load_golden("kat_simulation_experiment")
