@@ -464,9 +464,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     __builtin_amdgcn_s_waitcnt(0);   // C and the first chunk have landed
     __syncthreads();
 
-    // (Tried: the chunk's barrier in the middle of its MFMAs with a second fragment set, so that every
-    // LDS read is issued 16 MFMAs before its use -- correct, 3 % slower than this plain order; s_setprio 1 around
-    // the chunk's MFMAs -- 1 % slower.)
+    // (Tried: s_setprio 1 around the chunk's MFMAs -- 1 % slower.)
     // The DMA of chunk st + 2 is issued right BEHIND the barrier of chunk st -- into the stage chunk st has just been read
     // from -- and waited for in front of the barrier of chunk st + 1.  hipcc sinks the second half of a chunk's MFMAs below
     // its barrier, so with the DMA issued at the TOP of the next iteration (rounds 1-2) a transfer had only the first
@@ -485,30 +483,42 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     // The loop runs two chunks per iteration (the number of chunks is a multiple of 32), so that the LDS stage of a chunk
     // is a compile-time constant: the fragment reads take it as the immediate offset of ds_read_b128 instead of six vector
     // instructions per chunk that add it to the per-lane addresses.
+    // Two fragment sets: the reads of a half-chunk's fragments are issued in front of the OTHER half-chunk's sixteen MFMAs --
+    // the second half's (same stage) in front of the first half's MFMAs, the next chunk's first half (other stage, visible
+    // since this chunk's barrier) in front of the second half's -- so that no LDS round trip is exposed.  (Tried in round 3's
+    // first session with the barrier in mid-chunk: 3 % slower then, with ten vector instructions still in the loop; now
+    // trailing updates 287.8 -> 285.8 ms per factorisation.)
+    d2_t af0[4], bf0[WJ], af1[4], bf1[WJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af0[i] = *reinterpret_cast<const d2_t*>(lds + a_rd[0] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(lds + b_rd[0] + j * 2048);
     auto step = [&](auto cur_c, int st) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_c)::value;
         const char* sb = lds + cur * STAGE;
-        d2_t af[2][4], bf[2][WJ];
+        const char* sn = lds + (cur ^ 1) * STAGE;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int i = 0; i < 4; ++i) af1[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[1] + i * 2048);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[kb][i] = *reinterpret_cast<const d2_t*>(sb + a_rd[kb] + i * 2048);
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) bf[kb][j] = *reinterpret_cast<const d2_t*>(sb + b_rd[kb] + j * 2048);
-        }
-        // first half-chunk's MFMAs, then the barrier, then -- fenced, so that the scheduler cannot put the second
-        // half-chunk's MFMAs in front of it -- the DMA of chunk st + 2, then the second half-chunk
+        for (int j = 0; j < WJ; ++j) bf1[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[1] + j * 2048);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i][h], bf[0][j][h], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the next chunk is in LDS
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i][h], bf0[j][h], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): the next chunk has landed, this stage has been read
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < nst) CK_DMA_NEXT(cur);   // every wave has finished reading this stage
+        if (st + 2 < nst) CK_DMA_NEXT(cur);
+        if (st + 1 < nst) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af0[i] = *reinterpret_cast<const d2_t*>(sn + a_rd[0] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(sn + b_rd[0] + j * 2048);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -516,7 +526,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i][h], bf[1][j][h], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i][h], bf1[j][h], acc[i][j], 0, 0, 0);
     };
     for (int st = 0; st < nst; st += 2) {
         step(std::integral_constant<int, 0>{}, st);
