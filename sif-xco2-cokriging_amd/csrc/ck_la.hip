@@ -442,14 +442,18 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     // trailing updates 299.6 -> 297.3 ms per factorisation at N = 40 000, two interleaved pairs of runs.
     unsigned vo4[NDMA];
 #pragma unroll
-    for (int t = 0; t < NDMA; ++t) vo4[t] = ((t & 1) ? d_odd : d_even) + (unsigned)(8 * t * CK_NB) * 8u;
+    // (the four transfers of a chunk share one LDS base in M0: the instruction's immediate offset, 0 / 1024 / 2048 / 3072, counts
+    // on the LDS side AND on the memory side, so the per-lane offset registers carry the difference)
+    for (int t = 0; t < NDMA; ++t) vo4[t] = ((t & 1) ? d_odd : d_even) + (unsigned)(8 * t * CK_NB) * 8u - (unsigned)(t * 1024);
 #define CK_DMA_CHUNK(stage_, kbyte_)                                                                            \
     {                                                                                                           \
         const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                   \
             (void*)(unsigned long long)(stage_a ? Ab : Bb), (short)0, 0x7fffffff, 0x00020000);                  \
-        _Pragma("unroll") for (int t = 0; t < NDMA; ++t)                                                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (ck_lds_void*)(lds_w + (stage_) * STAGE + t * 1024), 16, \
-                                                     (int)vo4[t], (int)(kbyte_), 0, 0);                         \
+        ck_lds_void* lp_ = (ck_lds_void*)(lds_w + (stage_) * STAGE);                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lp_, 16, (int)vo4[0], (int)(kbyte_), 0, 0);               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lp_, 16, (int)vo4[1], (int)(kbyte_), 1024, 0);            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lp_, 16, (int)vo4[2], (int)(kbyte_), 2048, 0);            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lp_, 16, (int)vo4[3], (int)(kbyte_), 3072, 0);            \
     }
     CK_DMA_CHUNK(0, 0L);
     d4_t acc[4][WJ];
