@@ -200,6 +200,12 @@ int ck_factor_info(ck_handle* h, int64_t* info);
 int ck_predict_local(ck_handle* h, int i, const double* pcoords_host, int64_t m, double max_dist, int cv,
                      double* pred_host, double* pred_err_host, int64_t* n_empty, int64_t* n_not_pd,
                      int64_t* k_max);
+/* The reference builds the local predictor's state once, in its constructor (src/point_prediction.py:24-43: the Sigma blocks
+ * the neighbourhoods are gathered from).  Here that state is the scratch slab of the large-neighbourhood paths: nbytes > 0
+ * reserves at least that much, 0 the automatic budget of ck_predict_local (a quarter of the free device memory, at most
+ * 32 GiB; option "local_slab_mb" if set).  Afterwards no ck_predict_local whose batches fit pays a hipMalloc (tens of GiB
+ * right after smaller buffers were freed: up to seconds -- ck_timings [14] shows what a call spent growing the slab). */
+int ck_local_reserve(ck_handle* h, int64_t nbytes);
 
 /* ---- empirical (cross-)semivariogram / covariogram: src/fields.py:192-232, 378-403 ----- */
 /* Fields i and j: coords (n x 2), residuals = values minus their mean (src/fields.py:380).
@@ -286,6 +292,11 @@ int ck_debug_stream_overlap(ck_handle* h, int mode, int64_t rows, int n_side, do
  * (csrc/ck_tilemap.h): out3[3 t .. 3 t + 2] = block column, tile row and tile column inside it, for t < min(total, cap).
  * Returns the number of tiles = the launch's grid size, or -1. */
 int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, int32_t* out3, int64_t cap);
+/* Host only: the same for a launch over the TALL matrix [Sigma; c0^T; z^T] (ck_factor_predict, round 4: one launch updates a
+ * block column's triangle tiles and the aux_tile_rows x 4 tiles of the right-hand-side block below it):
+ * out4[4 t .. 4 t + 3] = block column, tile row, tile column, 1 if the tile lies in the right-hand-side block (tile row and
+ * column then count inside that block).  Returns the grid size, or -1. */
+int64_t ck_debug_tall_map(int64_t nvalid, int J0, int nJ, int aux_tile_rows, int32_t* out4, int64_t cap);
 /* Host only: the workgroups of a batched launch of the local predictor's tiled path over n_sys systems, largest first, with
  * counts[y] work units each (non-increasing): out2[2 b], out2[2 b + 1] = system (-1: a padding workgroup at the end of a
  * run of equal counts) and unit of workgroup b, for b < min(grid, cap).  Returns the grid size, or -1. */
@@ -304,7 +315,11 @@ int ck_debug_gemm_stamps(ck_handle* h, uint64_t* out_host, int64_t n_words, int6
  * a workgroup of the cooperative panel step (option "panel_fused" bit 4) timed out waiting for a pivot block (never
  * observed; the bit is then off for the handle); [13] after ck_factor_predict: the span of the two overlapped sweeps -- [1] is then the
  * factorisation's span inside it (it shares the chip with the substitution), [3] what the substitution adds behind the
- * factorisation's end, and [5] .. [8] are 0 (a launch's duration would include the other sweep's share of the chip). */
+ * factorisation's end, and [5] .. [8] are 0 (a launch's duration would include the other sweep's share of the chip) -- except
+ * in the tall sweep (option "tall_sweep", the default): [5]/[6] = sum of the durations / number of its update launches
+ * (k_tall_group_d; launches of the two streams overlap each other, so the sum exceeds the span); [10] counts device work only
+ * (counting pass + solve), [14] = host milliseconds the last ck_predict_local / ck_local_reserve spent growing the scratch slab
+ * (hipMalloc; 0 when it did not grow); [15] reserved. */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it
@@ -336,6 +351,14 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * sub-blocks as their pivot chunks are published through flags in device memory (agent-scope release / coherent loads,
  * bounded waits), so that a chunk waits for the one chunk above it in the dependency chain instead of for 24 launch
  * boundaries;
+ * "coop_spins" (default 2 000 000, ~2 s): polls a workgroup of that launch spends on one flag before it sets the error word and
+ * leaves (ck_factor / ck_factor_predict then repeat the factorisation with one launch per dependency and switch bit 4 off:
+ * ck_timings [12]); "coop_inject_panel" (default -1; tests): the cooperative step of that panel drops one flag store, once, so
+ * that the bounded wait trips and the recovery runs;
+ * "tall_sweep" (0/1, default 1): ck_factor_predict as ONE sweep over the tall matrix [Sigma; c0^T; z^T] -- the right-hand-side
+ * rows are further workgroups of the cooperative panel step and further tiles of every update launch (k_tall_group_d), with
+ * the look-ahead of "fused_la" -- instead of a factorisation and a substitution sweep that share the chip on two streams
+ * (same bits either way);
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
  * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by

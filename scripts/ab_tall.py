@@ -1,0 +1,57 @@
+"""A/B, interleaved in one process: ck_factor_predict as ONE sweep over the tall matrix [Sigma; c0^T; z^T] (round 4,
+option tall_sweep) against round 3's two overlapped sweeps and the plain sequence.
+
+    python scripts/ab_tall.py [n_obs=20000] [reps=3] [variants=a,b,..] [config=2|1]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sif_xco2_cokriging_amd import native, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+pb = synth.conus_problem(n, seed=20003) if cfg == 2 else synth.unit_square_problem(n, grid_side=100)
+pv = pb["params"]
+h = native.Handle(0)
+h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+h.set_metric(pb["metric"])
+for k in range(2):
+    h.set_data(k, pb["coords"][k], pb["values"][k])
+pc = pb["pcoords"]
+ref = None
+variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1}), ("tallT", {"tall_sweep": 1, "time_gemm": 1}),
+            ("tallG1", {"tall_sweep": 1, "fused_group": 1}), ("tallG2", {"tall_sweep": 1, "fused_group": 2}),
+            ("tallG4", {"tall_sweep": 1, "fused_group": 4}), ("tallG5", {"tall_sweep": 1, "fused_group": 5}),
+            ("tallG6", {"tall_sweep": 1, "fused_group": 6})]
+if len(sys.argv) > 3 and sys.argv[3] != "all":
+    variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
+N = 2 * n
+m = len(pc)
+flops = N ** 3 / 3 + N ** 2 * m
+for it in range(reps):
+    for mode, opts in variants:
+        h.set_option("fused_sweeps", 1)
+        h.set_option("fused_group", 0)
+        h.set_option("tall_sweep", 1)
+        h.set_option("time_gemm", 0)
+        for k_, v_ in opts.items():
+            h.set_option(k_, v_)
+        h.assemble_joint()
+        h.synchronize()
+        t0 = time.perf_counter()
+        if mode == "plain":
+            assert h.factor() == 0
+            pred, err = h.predict(0, pc)
+        else:
+            info, pred, err = h.factor_predict(0, pc)
+            assert info == 0
+        wall = (time.perf_counter() - t0) * 1e3
+        t = h.timings()
+        if ref is None:
+            ref = (pred, err)
+        dp = np.max(np.abs(pred - ref[0])) / np.max(np.abs(ref[0]))
+        de = np.max(np.abs(err - ref[1])) / np.max(np.abs(ref[1]))
+        both = t['fused_sweeps_ms'] if mode != 'plain' else t['factor_ms'] + t['solve_ms']
+        print(f"N={N} m={m} {mode:7s} wall {wall:7.1f} ms | sweeps {both:7.1f} ms = {flops / both / 1e9 / 78.6:.3f} of peak | "
+              f"launches {t['syrk_launches']:.0f} sum {t['syrk_ms']:.1f} ms | diff pred {dp:.1e} err {de:.1e}", flush=True)

@@ -159,7 +159,7 @@ struct ck_handle {
     int64_t vg_stats[4] = {0, 0, 0, 0};   // host-decided pairs of the extent pass | of the binning pass | pairs visited by
                                           // the binning pass | extra extent rounds
     // timings
-    double t_ms[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double t_ms[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int time_gemm = 0;   // 1: bracket every trailing-update launch with events | 2: the Sigma updates only (step-wise form)
     std::vector<EvPair> gemm_ev;
     size_t gemm_ev_used = 0;
@@ -171,6 +171,7 @@ struct ck_handle {
     int fused_sweeps_opt = -1;        // ck_factor_predict: -1 automatic (overlapped up to 128 panels) | 0 sequential | 1 overlapped
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
+    int tall_sweep = 1;               // ck_factor_predict: ONE sweep over the tall matrix [Sigma; c0^T; z^T] (tall_sweeps, round 4)
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
@@ -205,6 +206,8 @@ struct ck_handle {
     int64_t stamp_grid[4] = {0, 0, 0, 0};     // grid x, y, J0, panels of the last stamped launch
     int stamp_sel = 0;                        // 1: every launch | >= 2: only the trailing launch behind panel group K0 = stamp_sel - 2
     unsigned coop_seq = 0;
+    unsigned coop_spins = 2000000;    // option "coop_spins": polls a workgroup of k_panel_coop spends on one flag before it gives up (~2 s)
+    int coop_inject_panel = -1;       // option "coop_inject_panel" (tests): the cooperative step of this panel loses one flag store
 };
 
 extern "C" int ck_version(void) { return 100; }
@@ -468,8 +471,12 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
 // (thread team, Hilbert order, bounding box, the reference's distance arithmetic, the variogram's level planning and tie
 // decisions: ck_host.cpp -- host-only code, also built with the CPU sanitizers by tests/test_host_sanitize.py)
 // Decide the padded layout, upload sites / values, allocate the owned panels.
-static int ensure_layout(ck_handle* h) {
-    if (h->layout_ready) return 0;
+// need_panels = false (ck_predict_local): sites, tables and chunk bounds only -- the local predictor never touches the Sigma
+// panels or the receive buffers (a rank pool's local handle used to hold its share of a 40 GB Sigma beside the
+// joint runner's arena); they are allocated by the first entry that needs them.
+static int ensure_panels(ck_handle* h);
+static int ensure_layout(ck_handle* h, bool need_panels = true) {
+    if (h->layout_ready) return need_panels ? ensure_panels(h) : 0;
     if (!h->model_set) return fail("ck_set_model has not been called");
     for (int k = 0; k < h->n_procs; ++k)
         if (!h->data_set[k]) return fail("ck_set_data missing for process " + std::to_string(k));
@@ -523,7 +530,12 @@ static int ensure_layout(ck_handle* h) {
     // squared bounding-box diagonal of the data sites (Euclidean table range)
     const double qbox = (bhi[0] - blo[0]) * (bhi[0] - blo[0]) + (bhi[1] - blo[1]) * (bhi[1] - blo[1]);
     if (build_tables(h, qbox)) return -1;
-    // panels
+    h->layout_ready = true;
+    return need_panels ? ensure_panels(h) : 0;
+}
+
+static int ensure_panels(ck_handle* h) {
+    const int64_t Np = h->Npad;
     if (h->sig.empty()) {
         h->sig.assign(h->nK, nullptr);
         // the owned panels from ONE allocation (outside a caller's arena, where dev_alloc carves anyway): 79 hipMalloc /
@@ -568,7 +580,6 @@ static int ensure_layout(ck_handle* h) {
             HIPCHK(hipMemcpy(h->d_panelptr, pp.data(), h->nK * sizeof(double*), hipMemcpyHostToDevice));
         }
     }
-    h->layout_ready = true;
     return 0;
 }
 
@@ -803,7 +814,9 @@ static void syrk_update(ck_handle* h, hipStream_t st, int K0, int np, int J0, in
     ck_launch_syrk_group(st, h->d_sigptr, h->d_panelptr, K0, np, J0, Jstep, nJ, h->Npad, h->nend, stamps);
 }
 
-static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
+// with_aux (the tall sweep, cooperative panel step only): the right-hand-side rows of block column K walk through the panel as
+// further workgroups of the same launch
+static void panel_factor_on(ck_handle* h, int K, hipStream_t st, bool with_aux = false) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
     double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
@@ -811,7 +824,13 @@ static void panel_factor_on(ck_handle* h, int K, hipStream_t st) {
         // the whole panel step in ONE launch of cooperating workgroups (ck_la.hip: k_panel_coop): a chunk of rows waits for
         // the one chunk above it in the chain instead of for 24 grid-wide launch boundaries
         h->coop_seq += 1;
-        ck_launch_panel_coop(st, P, R, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16);
+        int drop = -1;
+        if (h->coop_inject_panel == K) {   // test hook (option "coop_inject_panel"): chunk 3 of this panel never publishes, once
+            drop = 3;
+            h->coop_inject_panel = -1;
+        }
+        ck_launch_panel_coop(st, P, R, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16,
+                             with_aux ? h->aux + (int64_t)K * h->mpad * CK_NB : nullptr, with_aux ? h->mpad : 0, h->coop_spins, drop);
         return;
     }
     if (h->panel_fused & 4) {
@@ -1006,12 +1025,21 @@ extern "C" int ck_panel_aux_solve(ck_handle* h, int K) {
     return 0;
 }
 
+// the info word alone (ck_factor / ck_factor_predict look at the cooperative step's error word themselves)
+static int factor_info_raw(ck_handle* h, int64_t* info) {
+    long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *info = external_index(h, (int64_t)v);   // pivots inside the identity padding cannot fail
+    return 0;
+}
+
 extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     CHKH(h);
     long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_info, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->world > 1 && (h->panel_fused & 16)) {   // step-wise form: a timed-out cooperative panel step is an error here
+    if (h->panel_fused & 16) {                     // step-wise form: a timed-out cooperative panel step is an error here
         unsigned werr = 0;                         // (ck_factor repeats the factorisation instead)
         HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
         if (werr != 0) {
@@ -1228,6 +1256,61 @@ static int fused_sweeps_la(ck_handle* h) {
     return 0;
 }
 
+// ONE sweep over the tall matrix [Sigma; c0^T; z^T] (round 4, option "tall_sweep"): the forward substitution is the panel
+// step applied to more rows, so every launch of the factorisation takes the right-hand-side rows along --
+// the cooperative panel step as further workgroups (k_panel_coop), the updates as further tiles of the same grid
+// (k_tall_group_d) -- instead of a second sweep that shares the chip with the first (fused_sweeps_la: 156 big launches per
+// pass on two streams, the substitution's one-column launches filling 280 of 512 slots).  The look-ahead is kept: stream C
+// (high priority) carries the chain of group g and A(g), the update of the NEXT group's block columns by group g; stream T
+// carries B1(g) = group g -> block columns of group g + 2 and B2(g) = group g -> everything beyond.  Every block column --
+// of Sigma and of the right-hand-side rows -- receives its updates in the order of the sequential sweeps, each in one launch
+// with K = 512 G, and every tile computes what it computed there: same bits as ck_factor + ck_predict.
+//   C:  chain(g) -> [ev_pan g] -> wait B1(g - 1) -> A(g) -> chain(g + 1) ...
+//   T:  wait ev_pan g -> B1(g) -> [ev_col g] -> B2(g) -> wait ev_pan g + 1 ...
+static int tall_sweeps(ck_handle* h) {
+    if (ensure_events(h)) return -1;
+    if (!h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
+    hipStream_t C = h->side, T = h->side_lo, M = h->stream;
+    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    const int ng = (h->nK + G - 1) / G;
+    auto first = [&](int g) { return g * G; };
+    auto count = [&](int g) { return std::min(G, h->nK - g * G); };
+    auto update = [&](hipStream_t st, int K0, int np, int J0, int nJ) {
+        if (nJ <= 0) return;
+        gemm_timed_begin(h, st);
+        ck_launch_tall_group(st, h->d_sigptr, h->aux, h->mpad, K0, np, J0, nJ, h->nend);
+        gemm_timed_end(h, st);
+    };
+    HIPCHK(hipEventRecord(h->ev0, M));
+    HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
+    HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
+    for (int g = 0; g < ng; ++g) {
+        const int K0 = first(g), Gc = count(g);
+        for (int q = 0; q < Gc; ++q) {
+            if (q > 0) update(C, K0, q, K0 + q, 1);
+            panel_factor_on(h, K0 + q, C, true);
+        }
+        HIPCHK(hipEventRecord(h->ev_pan[g], C));   // group g's panels and right-hand-side block columns are final
+        if (g + 1 < ng) {
+            if (g >= 1) HIPCHK(hipStreamWaitEvent(C, h->ev_col[g - 1], 0));   // B1(g - 1) wrote the same block columns
+            update(C, K0, Gc, first(g + 1), count(g + 1));                    // A(g)
+        }
+        HIPCHK(hipStreamWaitEvent(T, h->ev_pan[g], 0));
+        if (g + 2 < ng) {
+            update(T, K0, Gc, first(g + 2), count(g + 2));                    // B1(g)
+            HIPCHK(hipEventRecord(h->ev_col[g], T));
+        }
+        if (g + 3 < ng) update(T, K0, Gc, first(g + 3), h->nK - first(g + 3));   // B2(g)
+    }
+    HIPCHK(hipEventRecord(h->ev1, C));               // end of the chain: the last panel is final
+    HIPCHK(hipEventRecord(h->ev2, T));
+    HIPCHK(hipStreamWaitEvent(M, h->ev1, 0));
+    HIPCHK(hipStreamWaitEvent(M, h->ev2, 0));
+    HIPCHK(hipEventRecord(h->ev3, M));               // end of everything
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ck_assemble_joint must have been called; = ck_factor + ck_predict with the two sweeps overlapped.  *info != 0: Sigma is not
 // positive definite (pred / pred_err untouched), reported exactly as ck_factor reports it.
 extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int64_t m, double* pred, double* pred_err,
@@ -1250,18 +1333,31 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     if (ck_aux_begin(h, i, pcoords, m)) return -1;
     h->gemm_ev_used = 0;
     const bool la = h->fused_la >= 0 ? h->fused_la != 0 : h->nK >= 40;
-    if (la ? fused_sweeps_la(h) : fused_sweeps(h)) return -1;
-    if (ck_factor_info(h, info)) return -1;
+    const bool tall = (h->panel_fused & 16) && h->tall_sweep != 0;
+    if (tall ? tall_sweeps(h) : la ? fused_sweeps_la(h) : fused_sweeps(h)) return -1;
+    if (factor_info_raw(h, info)) return -1;
     unsigned werr = 0;
     HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
     if (*info != 0 || werr != 0) {
         // not positive definite, or a cooperative panel step timed out: ck_factor's own handling (redo in the caller's
-        // order for numpy's minor index / without the cooperative step), then the substitution on the finished factor
+        // order for numpy's minor index / without the cooperative step), then the substitution on the finished factor.
+        // A timed-out step: clear its error word and switch the cooperative step off HERE, so that ck_factor runs the
+        // factorisation once, the plain way, instead of repeating a cooperative one and discarding it for the stale flag.
+        if (werr != 0) {
+            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
+            h->panel_fused &= ~16;
+        }
+        h->gemm_ev_used = 0;
         h->assembled = false;
         h->aux_state = 0;
         if (ck_assemble_joint(h)) return -1;
         if (ck_factor(h, info)) return -1;
-        return *info == 0 ? ck_predict(h, i, pcoords, m, pred, pred_err) : 0;
+        if (werr != 0) h->t_ms[12] = 1.0;   // visible in ck_timings: the factorisation was redone
+        if (*info != 0) return 0;
+        const double redone = h->t_ms[12];
+        if (ck_predict(h, i, pcoords, m, pred, pred_err)) return -1;
+        h->t_ms[12] = redone;
+        return 0;
     }
     h->factored = true;
     float ms = 0;
@@ -1272,6 +1368,8 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     h->t_ms[3] = h->t_ms[13] - h->t_ms[1];   // what the substitution adds behind the factorisation
     h->t_ms[12] = 0.0;
     h->t_ms[5] = h->t_ms[6] = h->t_ms[7] = h->t_ms[8] = 0.0;
+    if (tall) gemm_timed_collect(h, 5);   // the tall sweep's update launches (sum of their durations; they overlap each other)
+    else h->gemm_ev_used = 0;
     if (ck_aux_finish(h, pred, pred_err)) return -1;
     h->aux_state = 2;
     return 0;
@@ -1283,8 +1381,26 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
     if (!h->assembled) return fail("ck_assemble_joint has not been called");
     if (h->factored) return fail("Sigma is already factored; call ck_assemble_joint again");
     h->aux_state = 0;
+    h->t_ms[12] = 0.0;
     if (factor_sweep(h)) return -1;
-    if (ck_factor_info(h, info)) return -1;
+    {
+        // FIRST the cooperative panel step's error word: a workgroup of k_panel_coop that gave up waiting for a pivot block
+        // (bounded spin, option "coop_spins": ~2 s; never observed outside the test hook "coop_inject_panel") leaves a factor --
+        // and an info word -- that are not to be trusted.  The cooperative step is switched off for this handle and the
+        // factorisation repeated with one launch per dependency.
+        HIPCHK(hipStreamSynchronize(h->stream));
+        unsigned werr = 0;
+        HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+        if (werr != 0) {
+            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
+            h->panel_fused &= ~16;
+            h->assembled = false;
+            if (ck_assemble_joint(h)) return -1;
+            if (factor_sweep(h)) return -1;
+            h->t_ms[12] = 1.0;                  // visible in ck_timings
+        }
+    }
+    if (factor_info_raw(h, info)) return -1;
     if (*info != 0 && h->site_order) {
         // Not positive definite.  numpy names the failing leading minor of Sigma in the CALLER's
         // order (cho_factor, joint_prediction.py:68-69, raises LinAlgError): redo the factorisation in that
@@ -1294,31 +1410,12 @@ extern "C" int ck_factor(ck_handle* h, int64_t* info) {
         h->assembled = false;
         if (ck_assemble_joint(h)) return -1;
         if (factor_sweep(h)) return -1;
-        if (ck_factor_info(h, info)) return -1;
+        if (factor_info_raw(h, info)) return -1;
     }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->t_ms[1] = ms;
     gemm_timed_collect(h, 5);
-    {
-        unsigned werr = 0;
-        HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
-        h->t_ms[12] = 0.0;
-        if (werr != 0) {
-            // a workgroup of k_panel_coop gave up waiting for a pivot block (bounded spin: ~2 s; never observed): the factor
-            // is not to be trusted.  The cooperative panel step is switched off for this handle and the factorisation
-            // repeated with one launch per dependency.
-            HIPCHK(hipMemset(h->d_coop + 16, 0, sizeof(unsigned)));
-            h->panel_fused &= ~16;
-            h->assembled = false;
-            if (ck_assemble_joint(h)) return -1;
-            if (factor_sweep(h)) return -1;
-            if (ck_factor_info(h, info)) return -1;
-            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-            h->t_ms[1] = ms;
-            h->t_ms[12] = 1.0;                  // visible in ck_timings
-        }
-    }
     h->factored = true;
     return 0;
 }
@@ -1721,7 +1818,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
                                 double* pred, double* pred_err, int64_t* n_empty, int64_t* n_not_pd,
                                 int64_t* k_max) {
     CHKH(h);
-    if (ensure_layout(h)) return -1;
+    if (ensure_layout(h, false)) return -1;   // sites, tables, chunk bounds -- no Sigma panels
     if (i < 0 || i >= h->n_procs) return fail("process index out of range");
     if (m < 0 || (m > 0 && !pcoords)) return fail("bad pcoords");
     if (n_empty) *n_empty = 0;
@@ -1756,6 +1853,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
     ck_launch_local_count(h->stream, h->metric, i, cv ? 1 : 0, max_dist, d_p3, m, mp, h->s0, layout_of(h), d_cnt,
                           h->d_chunkb, cmax, d_pu);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));   // [ev0, ev1]: the counting pass; the host-side planning and a growth of the
+                                                 // scratch slab (hipMalloc: up to seconds) lie between the two device windows
     std::vector<int> cnt(m);
     HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1834,6 +1933,8 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             slab_doubles = acc > slab_doubles ? acc : slab_doubles;
         }
     }
+    h->t_ms[14] = 0.0;
+    const auto t_grow = std::chrono::steady_clock::now();
     if (slab_doubles > h->local_slab_doubles) {
         // Growing is what stalls: hipMalloc of tens of GiB right after a hipFree of a few GiB that were written
         // took 1-4 s every time (scripts/diag_malloc.py).  So: beyond 1 GiB take the whole budget at once (the
@@ -1852,8 +1953,12 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             h->local_slab_doubles = want;
         }
         h->local_slab = fresh;
+        // visible in ck_timings [14]; profiles/r03c_local_predictor.json's 100 km row (1 262 ms for a 3 ms call) was this
+        // allocation inside the one event window of round 3
+        h->t_ms[14] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_grow).count();
     }
     if (slab_doubles > 0) d_slab = h->local_slab;
+    HIPCHK(hipEventRecord(h->ev2, h->stream));
     HIPCHK(hipMemcpyAsync(d_off, off.data(), m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     const double c0var = h->blk[2 * i].amp + h->blk[2 * i].nugget;   // covariance(i, 0)[0], point_prediction.py:66
     const int use_tab = tables_usable(h) ? 1 : 0;
@@ -1895,19 +2000,47 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
         }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventRecord(h->ev3, h->stream));
     HIPCHK(hipMemcpyAsync(pred, d_out, m * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pred_err, d_out + mp, m * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    float ms = 0;
+    float ms = 0, ms2 = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->t_ms[10] = ms;
+    HIPCHK(hipEventElapsedTime(&ms2, h->ev2, h->ev3));
+    h->t_ms[10] = (double)ms + (double)ms2;   // device work: counting pass + assembly / factorisations / reductions
     int64_t npd = 0;
     for (int64_t p = 0; p < m; ++p)
         if (cnt[p] > 0 && pred[p] != pred[p]) ++npd;
     if (n_empty) *n_empty = nempty;
     if (n_not_pd) *n_not_pd = npd;
     if (k_max) *k_max = kmx;
+    return 0;
+}
+
+// The reference builds the local predictor's state once, in its constructor (src/point_prediction.py:24-43: the full Sigma
+// blocks); here that state is the scratch slab of the large-neighbourhood paths.  nbytes > 0: at least that much; 0: the
+// automatic budget of ck_predict_local (a quarter of the free memory, at most 32 GiB; option "local_slab_mb" if set).  After
+// this call no ck_predict_local whose batches fit pays a hipMalloc.
+extern "C" int ck_local_reserve(ck_handle* h, int64_t nbytes) {
+    CHKH(h);
+    if (nbytes < 0) return fail("ck_local_reserve: negative size");
+    long long want = nbytes / 8;
+    if (nbytes == 0) {
+        size_t mem_free = 0, mem_total = 0;
+        HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+        mem_free += (size_t)h->local_slab_doubles * 8;
+        want = (long long)std::min<size_t>(mem_free / 4, (size_t)32 << 30) / 8;
+        if (h->local_slab_mb > 0) want = (long long)h->local_slab_mb * (1 << 20) / 8;
+    }
+    if (want <= h->local_slab_doubles) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->local_slab) (void)hipFree(h->local_slab);
+    h->local_slab = nullptr;
+    h->local_slab_doubles = 0;
+    HIPCHK(hipMalloc((void**)&h->local_slab, (size_t)want * 8));
+    h->local_slab_doubles = want;
+    h->t_ms[14] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 
@@ -2594,6 +2727,21 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         h->fused_prio = (int)value;
         return 0;
     }
+    if (!strcmp(name, "coop_spins")) {
+        if (value < 1000 || value > 2000000000LL) return fail("coop_spins must be in [1000, 2e9]");
+        h->coop_spins = (unsigned)value;
+        return 0;
+    }
+    if (!strcmp(name, "coop_inject_panel")) {   // tests: the bounded wait of k_panel_coop must trip and be recovered from
+        if (value < -1) return fail("coop_inject_panel must be -1 (off) or a panel index");
+        h->coop_inject_panel = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "tall_sweep")) {   // see ck_handle::tall_sweep
+        if (value < 0 || value > 1) return fail("tall_sweep must be 0 or 1");
+        h->tall_sweep = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "fused_la")) {
         if (value < -1 || value > 1) return fail("fused_la must be -1 (automatic), 0 or 1");
         h->fused_la = (int)value;
@@ -2681,7 +2829,7 @@ extern "C" int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count) {
 
 extern "C" int ck_timings(ck_handle* h, double* out, int n) {
     CHKH(h);
-    for (int k = 0; k < n && k < 14; ++k) out[k] = h->t_ms[k];
+    for (int k = 0; k < n && k < 16; ++k) out[k] = h->t_ms[k];
     return 0;
 }
 

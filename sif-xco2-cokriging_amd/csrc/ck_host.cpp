@@ -206,6 +206,25 @@ extern "C" int64_t ck_debug_tile_map(int64_t nvalid, int J0, int Jstep, int nJ, 
     return m.total;
 }
 
+// host-only: the same for a "tall" launch (k_tall_group_d): every block column's triangle tiles are followed by the
+// aux_tile_rows x 4 tiles of the right-hand-side block below it; out4 = (block column, tile row, tile column, 1 if the
+// tile belongs to the right-hand-side block)
+extern "C" int64_t ck_debug_tall_map(int64_t nvalid, int J0, int nJ, int aux_tile_rows, int32_t* out4, int64_t cap) {
+    if (nvalid <= 0 || J0 < 0 || nJ < 0 || aux_tile_rows < 0) return ck_fail("bad arguments");
+    if (4LL * J0 >= (nvalid + 127) / 128) return ck_fail("block column J0 lies in the padding");
+    const CkTileMap m = ck_tilemap_make(nvalid, J0, 1, nJ, aux_tile_rows);
+    if (out4)
+        for (int64_t t = 0; t < m.total && t < cap; ++t) {
+            int u, tm, tn;
+            const bool ax = ck_tilemap_get(m, t, u, tm, tn);
+            out4[4 * t] = J0 + u;
+            out4[4 * t + 1] = tm;
+            out4[4 * t + 2] = tn;
+            out4[4 * t + 3] = ax ? 1 : 0;
+        }
+    return m.total;
+}
+
 // host-only: workgroup -> (system, unit) of a batched launch over systems with counts[y] units each (ck_tilemap.h)
 extern "C" int64_t ck_debug_run_map(const int32_t* counts, int n_sys, int32_t* out2, int64_t cap) {
     if (n_sys < 0 || (n_sys > 0 && !counts)) return ck_fail("bad arguments");

@@ -85,8 +85,14 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
                           unsigned long long* stamps = nullptr /* diagnostic: ck_debug_gemm_clock */);
 // the whole panel step (diagonal blocks, inverses, row solves, panel-internal updates) in ONE launch: nrows / 64 workgroups
 // that hand each other the pivot blocks through flags[0..7] == seq (ck_la.hip: k_panel_coop); *err != 0: a wait timed out
+// X / xrows (round 4): right-hand-side rows of this block column, further workgroups of the same launch (null / 0: none)
 void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,
-                          unsigned seq, unsigned* err);
+                          unsigned seq, unsigned* err, double* X = nullptr, int64_t xrows = 0, unsigned spins = 2000000u,
+                          int drop = -1 /* tests: this chunk of the diagonal block never publishes */);
+// one update of the TALL matrix [Sigma; c0^T; z^T]: block columns J0 .. J0 + nJ - 1 of Sigma and of the mpad right-hand-side
+// rows by the panels K0 .. K0 + np - 1, one launch (ck_la.hip: k_tall_group_d)
+void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux, int64_t mpad, int K0, int np, int J0, int nJ,
+                          int64_t nvalid);
 // diagnostic: the cooperative panel step with shader-clock stamps of its links 1 .. 7 (prof: 64 words)
 void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
                                unsigned* flags, unsigned seq, unsigned* err, long long* prof);

@@ -601,6 +601,53 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(
     gemm_tile_d<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
 }
 
+// ---------------------------------------------------------------------------------------
+// The TALL matrix [Sigma; c0^T; z^T] (round 4): one launch per update, triangle and right-hand-side tiles together
+// ---------------------------------------------------------------------------------------
+// The forward substitution of the right-hand-side rows IS the panel step applied to more rows, and a
+// block column's right-hand-side tiles take the same B operand rows (L panel rows of block column J) as its triangle tiles.
+// Rounds 1-3 ran them as two kernels (k_syrk_group_d, k_aux_group_d) -- in ck_factor_predict on two streams that share the
+// chip, 156 launches per pass, each with its own fill and drain, the one-column right-hand-side launches filling 280 of 512
+// slots.  Here a launch's grid is the tiles of both (ck_tilemap.h: axr), column by column, so that a block column's B rows
+// meet all their readers in one XCD's L2.  Every tile computes exactly what it computed before (same operands, same K
+// order): the results keep their bits.
+struct CkSrcTall {
+    double* const* sigptr;
+    const double* aux;
+    long mpad;
+    int K0, J;
+    long r0, c0;
+    bool ax;   // wave-uniform: this tile belongs to the right-hand-side block
+    __device__ __forceinline__ void get(int p, const ck_gchar*& A, const ck_gchar*& B) const {
+        const double* base = sigptr[K0 + p] + (long)(J - K0 - p) * CK_NB * CK_NB;
+        const double* arow = ax ? aux + (long)(K0 + p) * mpad * CK_NB : base;
+        A = as_global(reinterpret_cast<const char*>(arow + r0 * CK_NB));
+        B = as_global(reinterpret_cast<const char*>(base + c0 * CK_NB));
+    }
+};
+
+__global__ __launch_bounds__(512, 4) void k_tall_group_d(double* const* __restrict__ sigptr, double* __restrict__ aux, long mpad,
+                                                          int K0, int np, const CkTileMap map) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    int u, tm, tn;
+    const bool ax = ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
+    const int J = map.J0 + u * map.Jstep;
+    const long r0 = (long)tm * 128, c0 = (long)tn * 128;
+    const CkSrcTall src{sigptr, aux, mpad, K0, J, r0, c0, ax};
+    double* C = ax ? aux + (long)J * mpad * CK_NB : sigptr[J];
+    gemm_tile_d<8>(C, CK_NB, src, np, r0, c0, lds);
+}
+
+// block columns J0 .. J0 + nJ - 1 of Sigma (lower tiles in front of the padding) and of the mpad right-hand-side rows, by the
+// panels K0 .. K0 + np - 1 (single process: every panel in its own storage)
+void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux, int64_t mpad, int K0, int np, int J0, int nJ,
+                          int64_t nvalid) {
+    if (nJ <= 0 || np <= 0) return;
+    const CkTileMap map = ck_tilemap_make(nvalid, J0, 1, nJ, (int)(mpad / 128));
+    if (map.total <= 0) return;
+    k_tall_group_d<<<dim3((unsigned)map.total), dim3(512), 0, s>>>(sigptr_dev, aux, (long)mpad, K0, np, map);
+}
+
 // Schur complement of the prediction sites, S = C_pp - V^T V (ck_verify_model): the solved right-hand-side rows
 // V^T (one row per prediction site, block column p of the data sites at aux + p * mpad * NB) are both operands;
 // block column J of S (rows J * NB .., packed like a Sigma panel) -= sum over ALL np data block columns in one
@@ -1301,13 +1348,12 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const doub
 // first version of this kernel published with __threadfence(): ~3.5 us twice per link of the chain).  No workgroup reads
 // a byte of another chunk's rows or of an inverse before its flag, so no XCD's L2 can hold an older copy of them.
 // Waits are bounded (a timeout sets *err, the host then repeats the factorisation the old way).
-#define CK_COOP_SPINS 2000000
-__device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, unsigned* err) {
+__device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, unsigned* err, unsigned spins) {
     __shared__ int ok_s;
     __syncthreads();            // the previous use of ok_s has been read by everybody
     if (threadIdx.x == 0) {
         int ok = 0;
-        for (int spin = 0; spin < CK_COOP_SPINS; ++spin) {
+        for (unsigned spin = 0; spin < spins; ++spin) {
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
                 ok = 1;
                 break;
@@ -1322,47 +1368,67 @@ __device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, un
 }
 
 // The two halves of lt_rows_body for the chunk that is next in the chain (its pivot block is being factored right now):
-//   coop_accumulate  cn = C - sum_{ks < i} A_ks B_ks^T, everything that does not need the pivot block's inverse -- runs
+//   coop_accumulate  cn = -(C - sum_{ks < i} A_ks B_ks^T), everything that does not need the pivot block's inverse -- runs
 //                    while the pivot chunk's workgroup is still inside potrf64_body;
-//   coop_finish      X = cn Linv^T once the inverse is published; X goes to memory AND stays in Xs (LDS, 64 x 66) for
+//   coop_finish      X = -(cn Linv^T) once the inverse is published; X goes to memory AND stays in Xs (LDS, 64 x 66) for
 //                    the last slab of the chunk's own diagonal update.
+// Round 4: every global access of the two is a buffer instruction -- the rows in a resource descriptor (scalar registers), ONE
+// per-lane offset register, the row group's and the slab's byte offset as the scalar offset -- as in lt_rows_body; what other
+// workgroups of this launch wrote (pivot rows, inverse) is loaded with sc1, what they will read is stored with sc1 (the same
+// cache policy as the agent-scope atomic loads / stores of round 3).  Before, each of a slab's 32 eight-byte loads per
+// thread had its own 64-bit address: sixteen address pairs per operand lived in VGPRs across the K loop, the kernel sat at
+// its 256-register budget with 6 of them spilled, and every reload of a spilled address carried an s_waitcnt vmcnt(0) into the
+// middle of the slab's loads -- on the chain this kernel exists to shorten.  The sign sits in the accumulators (-C in,
+// negated once in front of the store), so A goes to LDS as it is: sixteen v_xor per slab and thread gone as well.
+#define CK_SC1 16   // cache-policy bit of the buffer builtins on gfx940+: sc1 (coherent at agent scope)
+typedef unsigned ck_v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned ck_v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const double* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double coop_as_double(ck_v2u_t v) {
+    return __builtin_bit_cast(double, v);
+}
+
 __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __restrict__ C, const double* __restrict__ Ar,
                                                 const double* __restrict__ Br, int i, double* As, double* Bs) {
-    // (panel-local: every leading dimension is CK_NB, so a thread's sixteen elements of a slab sit at compile-time
-    // offsets from ONE per-thread address -- no pointer arrays in registers)
     constexpr int PITCH = 66;
-    constexpr long LD = CK_NB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int sr = tid >> 6, sc = tid & 63;
-    const double* at = Ar + sr * LD + sc;
-    const double* bt = Br + sr * LD + sc;
-    const double* ct = C + (16 * w + g) * LD + li;
-    double ra[16], rb[16];
+    constexpr int LD = CK_NB;
+    constexpr int RS = 8 * LD * 8;   // byte stride of a group of eight rows
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = tid >> 5, scp = tid & 31;   // staging: elements (srow + 8 u, 2 scp .. 2 scp + 1), u < 8
+    const __amdgpu_buffer_rsrc_t rsA = coop_rsrc(Ar), rsB = coop_rsrc(Br), rsC = coop_rsrc(C);
+    const int s_vo = (srow * LD + 2 * scp) * 8;
+    const int c_vo = ((16 * w + g) * LD + li) * 8;
+    double* const As_w = As + srow * PITCH + 2 * scp;
+    double* const Bs_w = Bs + srow * PITCH + 2 * scp;
+    ck_v4u_t ra[8], rb[8];
     if (i > 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            ra[u] = at[4 * u * LD];
-            rb[u] = ld_shared_result<true>(bt + 4 * u * LD);
+        for (int u = 0; u < 8; ++u) {
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, u * RS, 0);          // this chunk's own earlier columns
+            rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, s_vo, u * RS, CK_SC1);     // the pivot chunk's rows
         }
     }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cn[jt][r] = ct[4 * r * LD + 16 * jt];
+        for (int r = 0; r < 4; ++r)
+            cn[jt][r] = -coop_as_double(__builtin_amdgcn_raw_buffer_load_b64(rsC, c_vo, (4 * r * LD + 16 * jt) * 8, 0));
     for (int ks = 0; ks < i; ++ks) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            As[(sr + 4 * u) * PITCH + sc] = -ra[u];
-            Bs[(sr + 4 * u) * PITCH + sc] = rb[u];
+        for (int u = 0; u < 8; ++u) {
+            *reinterpret_cast<ck_v4u_t*>(As_w + 8 * u * PITCH) = ra[u];
+            *reinterpret_cast<ck_v4u_t*>(Bs_w + 8 * u * PITCH) = rb[u];
         }
         __syncthreads();
         if (ks + 1 < i) {
-            at += 64;
-            bt += 64;
+            const int so = 64 * (ks + 1) * 8;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                ra[u] = at[4 * u * LD];
-                rb[u] = ld_shared_result<true>(bt + 4 * u * LD);
+            for (int u = 0; u < 8; ++u) {
+                ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, so + u * RS, 0);
+                rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, s_vo, so + u * RS, CK_SC1);
             }
         }
 #pragma unroll
@@ -1380,15 +1446,23 @@ template <bool PUB>
 __device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restrict__ C, const double* __restrict__ Linv,
                                             double* Xs, double* Bs) {
     constexpr int PITCH = 66;
-    constexpr long ld = CK_NB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-    const int sr = tid >> 6, sc = tid & 63;
+    constexpr int LD = CK_NB;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = tid >> 5, scp = tid & 31;
+    const __amdgpu_buffer_rsrc_t rsL = coop_rsrc(Linv), rsC = coop_rsrc(C);
+    const int l_vo = (srow * 64 + 2 * scp) * 8;
+    const int c_vo = ((16 * w + g) * LD + li) * 8;
+    double* const Bs_w = Bs + srow * PITCH + 2 * scp;
+    ck_v4u_t rl[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) Bs[(sr + 4 * u) * PITCH + sc] = ld_shared_result<true>(Linv + (sr + 4 * u) * 64 + sc);
+    for (int u = 0; u < 8; ++u) rl[u] = __builtin_amdgcn_raw_buffer_load_b128(rsL, l_vo, u * (8 * 64 * 8), CK_SC1);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xs[(16 * w + g + 4 * r) * PITCH + 16 * jt + li] = cn[jt][r];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<ck_v4u_t*>(Bs_w + 8 * u * PITCH) = rl[u];
     __syncthreads();
     d4_t x[4];
 #pragma unroll
@@ -1398,9 +1472,11 @@ __device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restr
         for (int s2 = 0; s2 < 4 * (jt + 1); ++s2)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * w + li) * PITCH + 4 * s2 + g], Bs[(16 * jt + li) * PITCH + 4 * s2 + g],
                                                       acc, 0, 0, 0);
-        x[jt] = acc;
+        x[jt] = -acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st_shared_result<PUB>(C + (long)(16 * w + g + 4 * r) * ld + 16 * jt + li, acc[r]);
+        for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ck_v2u_t, x[jt][r]), rsC, c_vo, (4 * r * LD + 16 * jt) * 8,
+                                                  PUB ? CK_SC1 : 0);
     }
     // this wave read only its own 16 rows of Xs (LDS accesses of one wave are served in order): overwrite them with X
 #pragma unroll
@@ -1429,12 +1505,15 @@ __device__ __forceinline__ void coop_slab_syrk(d4_t (&dacc)[4], const double* M)
 // PROF (diagnostic instantiation, ck_debug_coop_profile): shader-clock stamps of the links 1 .. 7 -- [0] rows flag of the
 // pivot chunk seen, [1] accumulation done, [2] inverse flag seen, [3] rows solved and stored, [4] drained + rows flag set,
 // [5] diagonal block updated, [6] factored + inverse stored, [7] drained + flag set
+// rows: the chunk's own 64 rows (ld = CK_NB) -- inside the panel for the chunks of Sigma, inside block column K of the
+// right-hand-side rows for the chunks that hang below it (round 4: the forward substitution's in-panel step is the same
+// walk through the eight sub-blocks, k_panel_rows_all's work as further workgroups of this launch)
 template <bool PROF, bool DIAG>
-__device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0, long long* info, unsigned* flags,
-                                                unsigned seq, unsigned* err, long long* prof, double* As, double* Bs) {
+__device__ __forceinline__ void panel_coop_body(double* P, double* rows, double* tail, long g0, long long* info, unsigned* flags,
+                                                unsigned seq, unsigned* err, long long* prof, double* As, double* Bs,
+                                                unsigned spins, int drop) {
     constexpr int NQ = CK_NB / 64;
     const int b = (int)blockIdx.x;
-    const long row0 = 64 * (long)b;
     const int nj = DIAG ? b : NQ;                   // sub-blocks this chunk is solved against
     constexpr bool diag = DIAG;                     // a chunk of the diagonal block: a link of the chain
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
@@ -1446,23 +1525,27 @@ __device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0
     // (the diagonal update runs on -D: dacc = -D + sum X X^T, the updated block is -dacc -- loaded here, while nothing
     // else is going on, and handed to the factorisation through LDS: no read-modify-write of D on the chain)
     d4_t dacc[4];
+    {
+        const __amdgpu_buffer_rsrc_t rsD = coop_rsrc(rows + 64 * (DIAG ? b : 0));
+        const int d_vo = ((16 * w + g) * CK_NB + li) * 8;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            dacc[jt][r] = DIAG ? -P[(row0 + 16 * w + g + 4 * r) * CK_NB + 64 * b + 16 * jt + li] : 0.0;
+            for (int r = 0; r < 4; ++r)
+                dacc[jt][r] = DIAG ? -coop_as_double(__builtin_amdgcn_raw_buffer_load_b64(rsD, d_vo, (4 * r * CK_NB + 16 * jt) * 8, 0)) : 0.0;
+    }
     for (int j = 0; j < nj; ++j) {
-        if (!coop_wait(flags + NQ + j, seq, err)) return;      // uniform
+        if (!coop_wait(flags + NQ + j, seq, err, spins)) return;      // uniform
         if (PROF && j == b - 1) CK_COOP_MARK(0)
         if (j) __threadfence_block();                     // sub-block j reads what this workgroup stored in sub-blocks < j
         __syncthreads();
         d4_t cn[4];
-        coop_accumulate(cn, P + row0 * CK_NB + 64 * j, P + row0 * CK_NB, P + (long)(64 * j) * CK_NB, j, As, Bs);
+        coop_accumulate(cn, rows + 64 * j, rows, P + (long)(64 * j) * CK_NB, j, As, Bs);
         if (PROF && j == b - 1) CK_COOP_MARK(1)
-        if (!coop_wait(flags + j, seq, err)) return;
+        if (!coop_wait(flags + j, seq, err, spins)) return;
         if (PROF && j == b - 1) CK_COOP_MARK(2)
         if (diag) {
-            coop_finish<true>(cn, P + row0 * CK_NB + 64 * j, tail + (long)j * 64 * 64, As, Bs);
+            coop_finish<true>(cn, rows + 64 * j, tail + (long)j * 64 * 64, As, Bs);
             if (PROF && j == b - 1) CK_COOP_MARK(3)
             if (j == b - 1) {
                 // this chunk's rows are final (every one of them stored write-through): drain the stores, then the next link
@@ -1474,11 +1557,11 @@ __device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0
             }
             coop_slab_syrk(dacc, As);       // the rows just solved (still in LDS) into the own diagonal update
         } else {
-            coop_finish<false>(cn, P + row0 * CK_NB + 64 * j, tail + (long)j * 64 * 64, As, Bs);
+            coop_finish<false>(cn, rows + 64 * j, tail + (long)j * 64 * 64, As, Bs);
         }
     }
     if (!diag) return;
-    double* D = P + row0 * CK_NB + 64 * b;
+    double* D = rows + 64 * b;
     double (*M)[66] = reinterpret_cast<double (*)[66]>(As);
     __syncthreads();                        // the last slab's reads of As are done
 #pragma unroll
@@ -1491,28 +1574,35 @@ __device__ __forceinline__ void panel_coop_body(double* P, double* tail, long g0
     CK_COOP_MARK(6)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the inverse (write-through stores) has left this CU
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // drop == b (tests, option "coop_inject_panel"): this chunk never announces its block -- the waits of the chunks below
+    // it must time out, set *err and leave, and the host must redo the factorisation without this kernel
+    if (threadIdx.x == 0 && drop != b) __hip_atomic_store(flags + b, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CK_COOP_MARK(7)
 }
 
+// nsig: 64-row chunks of the panel itself; workgroups nsig .. grid - 1 take the chunks of X (the right-hand-side rows of
+// this block column, may be null with grid == nsig)
 __global__ __launch_bounds__(256, 2) void k_panel_coop(double* P, double* tail, long g0, long long* info, unsigned* flags,
-                                                        unsigned seq, unsigned* err) {
+                                                        unsigned seq, unsigned* err, double* X, int nsig, unsigned spins, int drop) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
-    if (blockIdx.x < CK_NB / 64)
-        panel_coop_body<false, true>(P, tail, g0, info, flags, seq, err, nullptr, As, Bs);
+    const int b = (int)blockIdx.x;
+    if (b < CK_NB / 64)
+        panel_coop_body<false, true>(P, P + 64L * b * CK_NB, tail, g0, info, flags, seq, err, nullptr, As, Bs, spins, drop);
     else
-        panel_coop_body<false, false>(P, tail, g0, info, flags, seq, err, nullptr, As, Bs);
+        panel_coop_body<false, false>(P, b < nsig ? P + 64L * b * CK_NB : X + 64L * (b - nsig) * CK_NB, tail, g0, info, flags, seq,
+                                      err, nullptr, As, Bs, spins, -1);
 }
 
 __global__ __launch_bounds__(256, 2) void k_panel_coop_prof(double* P, double* tail, long g0, long long* info, unsigned* flags,
                                                              unsigned seq, unsigned* err, long long* prof) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
-    if (blockIdx.x < CK_NB / 64)
-        panel_coop_body<true, true>(P, tail, g0, info, flags, seq, err, prof, As, Bs);
+    const int b = (int)blockIdx.x;
+    if (b < CK_NB / 64)
+        panel_coop_body<true, true>(P, P + 64L * b * CK_NB, tail, g0, info, flags, seq, err, prof, As, Bs, 2000000u, -1);
     else
-        panel_coop_body<true, false>(P, tail, g0, info, flags, seq, err, prof, As, Bs);
+        panel_coop_body<true, false>(P, P + 64L * b * CK_NB, tail, g0, info, flags, seq, err, prof, As, Bs, 2000000u, -1);
 }
 
 void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
@@ -1520,10 +1610,14 @@ void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* 
     k_panel_coop_prof<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(P, tail, (long)g0, info, flags, seq, err, prof);
 }
 
+// X / xrows: right-hand-side rows of this block column that walk through the panel in the same launch (xrows a multiple of
+// 64; 0: the panel alone)
 void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info, unsigned* flags,
-                          unsigned seq, unsigned* err) {
+                          unsigned seq, unsigned* err, double* X, int64_t xrows, unsigned spins, int drop) {
     if (nrows <= 0) return;
-    k_panel_coop<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(P, tail, (long)g0, info, flags, seq, err);
+    if (!X) xrows = 0;
+    k_panel_coop<<<dim3((unsigned)((nrows + xrows) / 64)), dim3(256), 0, s>>>(P, tail, (long)g0, info, flags, seq, err, X,
+                                                                              (int)(nrows / 64), spins, drop);
 }
 
 void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail) {

@@ -30,18 +30,26 @@ struct CkTileMap {
     int nfull;        // leading columns with >= 4 valid tile rows
     int tv_last;      // valid tile rows (1..3) of the one short column behind them, 0 if there is none
     int a, d;         // tiles of the first column; a full column has d tiles fewer than the one before it
+    int axr;          // "tall" launches (round 4): tile rows of the right-hand-side block that hangs below every block column
+                      // ([Sigma; c0^T; z^T] is ONE tall matrix: k_tall_group_d), 0 = the triangle alone
     long long nfull_tiles, total;
 };
 
-CK_HD long long ck_tilemap_before(const CkTileMap& m, long long u) { return u * m.a - (long long)(m.d / 2) * u * (u - 1); }
+// tiles in front of column u: the triangle's a - d u' plus 4 axr right-hand-side tiles per column u' < u
+CK_HD long long ck_tilemap_before(const CkTileMap& m, long long u) {
+    return u * (m.a + 4LL * m.axr) - (long long)(m.d / 2) * u * (u - 1);
+}
 
 // nvalid: rows / columns from here on are identity padding.  Columns without a valid row are dropped.
-CK_HD CkTileMap ck_tilemap_make(long long nvalid, int J0, int Jstep, int nJ) {
+// aux_tile_rows > 0: every column is followed by its aux_tile_rows x 4 right-hand-side tiles (x tv_last in the short column:
+// the tile columns inside the identity padding have an exactly zero update)
+CK_HD CkTileMap ck_tilemap_make(long long nvalid, int J0, int Jstep, int nJ, int aux_tile_rows = 0) {
     CkTileMap m;
     m.J0 = J0;
     m.Jstep = Jstep;
     m.nfull = 0;
     m.tv_last = 0;
+    m.axr = aux_tile_rows;
     const long long R0v = (nvalid + 127) / 128;
     const long long tv0 = R0v - 4LL * J0;
     m.a = (int)(4 * tv0 - 6);
@@ -56,24 +64,32 @@ CK_HD CkTileMap ck_tilemap_make(long long nvalid, int J0, int Jstep, int nJ) {
         }
     }
     m.nfull_tiles = ck_tilemap_before(m, m.nfull);
-    m.total = m.nfull_tiles + (long long)m.tv_last * (m.tv_last + 1) / 2;
+    m.total = m.nfull_tiles + (long long)m.tv_last * (m.tv_last + 1) / 2 + (long long)m.tv_last * m.axr;
     return m;
 }
 
-// tile t (0 <= t < m.total) -> column index u (block column J0 + u Jstep), tile row tm and tile column tn inside it
-CK_HD void ck_tilemap_get(const CkTileMap& m, long long t, int& u, int& tm, int& tn) {
+// tile t (0 <= t < m.total) -> column index u (block column J0 + u Jstep), tile row tm and tile column tn inside it;
+// returns true for a tile of the column's right-hand-side block (tm, tn count inside that block then)
+CK_HD bool ck_tilemap_get(const CkTileMap& m, long long t, int& u, int& tm, int& tn) {
     long long local;
-    if (t >= m.nfull_tiles) {   // the short last column: a plain triangle
+    if (t >= m.nfull_tiles) {   // the short last column: a plain triangle (+ tv_last tile columns of right-hand-side tiles)
         u = m.nfull;
         local = t - m.nfull_tiles;
+        const long long tri = (long long)m.tv_last * (m.tv_last + 1) / 2;
+        if (local >= tri) {
+            local -= tri;
+            tm = (int)(local / m.tv_last);
+            tn = (int)(local - (long long)tm * m.tv_last);
+            return true;
+        }
         long long r = (long long)((sqrt(8.0 * (double)local + 1.0) - 1.0) * 0.5);
         while ((r + 1) * (r + 2) / 2 <= local) ++r;
         while (r * (r + 1) / 2 > local) --r;
         tm = (int)r;
         tn = (int)(local - r * (r + 1) / 2);
-        return;
+        return false;
     }
-    const double h = 0.5 * m.d, b = (double)m.a + h;
+    const double h = 0.5 * m.d, b = (double)m.a + 4.0 * m.axr + h;
     double disc = b * b - 2.0 * (double)m.d * (double)t;
     if (disc < 0) disc = 0;
     long long uu = (long long)((b - sqrt(disc)) / (double)m.d);
@@ -83,6 +99,13 @@ CK_HD void ck_tilemap_get(const CkTileMap& m, long long t, int& u, int& tm, int&
     while (uu > 0 && ck_tilemap_before(m, uu) > t) --uu;
     u = (int)uu;
     local = t - ck_tilemap_before(m, uu);
+    const long long tsig = (long long)m.a - (long long)m.d * uu;   // the column's triangle tiles come first
+    if (local >= tsig) {
+        local -= tsig;
+        tm = (int)(local >> 2);
+        tn = (int)(local & 3);
+        return true;
+    }
     if (local < 1) {
         tm = 0;
         tn = 0;
@@ -96,6 +119,7 @@ CK_HD void ck_tilemap_get(const CkTileMap& m, long long t, int& u, int& tm, int&
         tm = 3 + (int)((local - 6) >> 2);
         tn = (int)((local - 6) & 3);
     }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

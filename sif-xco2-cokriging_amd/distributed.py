@@ -101,10 +101,15 @@ class DistributedJoint:
       storage for G = 3 and autotune() times one pass of either schedule and keeps the faster."""
 
     def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True,
-                 exchange: str = "broadcast", panel_group=1):
+                 exchange: str = "broadcast", panel_group=1, rehearse_collectives: bool = False):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
         self.lookahead = bool(lookahead)
+        # rehearse_collectives: issue every collective of the multi-rank schedules even at world == 1 (a one-rank
+        # communicator: each call goes through the backend -- RCCL on a single GPU -- and moves nothing).  What a box with
+        # one GPU can execute of the nccl path: tests/test_gpu_distributed.py::test_rccl_single_rank_*.
+        self._comm = self.world > 1 or (bool(rehearse_collectives) and dist_module is not None)
+        self._rehearse = bool(rehearse_collectives)
         if exchange not in EXCHANGES + ("auto",):
             raise ValueError("exchange must be one of " + ", ".join(EXCHANGES + ("auto",)))
         self.exchange = exchange
@@ -206,9 +211,9 @@ class DistributedJoint:
         how = how or self.exchange
         if how == "auto":
             how = "broadcast"       # not calibrated (yet)
-        if how == "p2p" and (self.world < 3 or not hasattr(dist, "P2POp")):
+        if how == "p2p" and ((self.world < 3 and not self._rehearse) or not hasattr(dist, "P2POp")):
             how = "broadcast"
-        if how == "sag" and (self.world < 2 or not hasattr(dist, "all_gather_into_tensor")):
+        if how == "sag" and ((self.world < 2 and not self._rehearse) or not hasattr(dist, "all_gather_into_tensor")):
             how = "broadcast"
         if how == "broadcast":
             t = self._panel_tensor(K)
@@ -294,7 +299,7 @@ class DistributedJoint:
         it has run on gloo and through a host-staged facade, never on RCCL, and the first multi-GPU run should not
         depend on it."""
         import time
-        if self.world == 1 or self.exchange != "auto":
+        if not self._comm or self.exchange != "auto":
             return self.comm_info
         nK = self.h.num_panels()[0]
         K = nK // 2
@@ -303,21 +308,30 @@ class DistributedJoint:
         cands = ["broadcast"]
         if "sag" in want and hasattr(self.dist, "all_gather_into_tensor"):
             cands.append("sag")
-        if "p2p" in want and self.world >= 3 and hasattr(self.dist, "P2POp"):
+        if "p2p" in want and (self.world >= 3 or self._rehearse) and hasattr(self.dist, "P2POp"):
             cands.append("p2p")
         ms = []
         for how in cands:
+            # Every rank issues the SAME sequence of collectives whatever happens inside its own try block (a
+            # rank that swallowed an exception used to skip the barrier and the timed exchanges the others still issued).
+            # A failure is agreed on collectively -- one MAX all-reduce of a flag is the only collective that follows a try
+            # block -- and a candidate that failed anywhere is dropped everywhere; a failure inside the timed part, after
+            # everybody agreed the warm-up worked, propagates: the communicator is not to be trusted any more.
+            bad = 0.0
             try:
                 self._exchange(K, src, how=how)
                 self._sync()
-                self.dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    self._exchange(K, src, how=how)
-                self._sync()
-                ms.append((time.perf_counter() - t0) / reps * 1e3)
             except Exception:      # an exchange this backend cannot run is simply not a candidate
+                bad = 1.0
+            if self._reduce_max([bad])[0] > 0.0:
                 ms.append(float("inf"))
+                continue
+            self.dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self._exchange(K, src, how=how)
+            self._sync()
+            ms.append((time.perf_counter() - t0) / reps * 1e3)
         ms = self._reduce_max(ms)
         best = min(range(len(cands)), key=lambda k: ms[k])
         self.exchange = cands[best]
@@ -337,13 +351,13 @@ class DistributedJoint:
             self.G = G
             self.predict(i, pcoords)        # untimed: first use of a schedule (allocations, clocks)
             self._sync()
-            if self.world > 1:
+            if self._comm:
                 self.dist.barrier(group=self.group)
             t0 = time.perf_counter()
             res = self.predict(i, pcoords)
             self._sync()
             ms.append((time.perf_counter() - t0) * 1e3)
-        if self.world > 1:
+        if self._comm:
             ms = self._reduce_max(ms)
         self.G = 1 if ms[0] <= ms[1] else 3
         self.tune_info = {"panel_group": self.G, "pass_ms": {"G=1": round(ms[0], 2), "G=3": round(ms[1], 2)}}
@@ -409,7 +423,7 @@ class DistributedJoint:
                         h.panel_apply_group(N0, g, SIG, J, J)
                     h.panel_factor(J)
                 t1 = mk()
-                if world > 1:
+                if self._comm:
                     works[J] = self._exchange(J, J % world, async_op=True)
                 if Gc > 0:
                     h.panel_apply_group(K0, Gc, SIG, N0 + Gn, nK - 1, g, Gn)
@@ -447,14 +461,14 @@ class DistributedJoint:
         """The factor is resident (panel K in its owner's storage): every rank needs each panel once more for its own
         right-hand-side rows -- exchange of panel K + 1 under the substitution with panel K."""
         h, mk = self.h, self._marks.mark
-        work = self._exchange(0, 0, async_op=True) if self.world > 1 else None
+        work = self._exchange(0, 0, async_op=True) if self._comm else None
         for K in range(nK):
             t0 = mk()
             if work is not None:
                 work.wait()
             t1 = mk()
             nxt = K + 1
-            work = self._exchange(nxt, nxt % self.world, async_op=True) if (self.world > 1 and nxt < nK) else None
+            work = self._exchange(nxt, nxt % self.world, async_op=True) if (self._comm and nxt < nK) else None
             h.panel_apply(K, native.APPLY_AUX)
             t2 = mk()
             self._steps.append((t0, t0, t2, t2, t0, t1))
@@ -484,7 +498,7 @@ class DistributedJoint:
             self._sweep_solve_only(nK)
         elif self.G > 1:
             self._sweep_grouped(nK, self.G)
-        elif self.world > 1 and self.lookahead:
+        elif self._comm and self.lookahead:
             self._sweep_lookahead(nK)
         else:
             for K in range(nK):
@@ -493,15 +507,26 @@ class DistributedJoint:
                 if owner == self.rank:
                     h.panel_factor(K)
                 t1 = mk()
-                if self.world > 1:
+                if self._comm:
                     self._exchange(K, owner)
                 t2 = mk()
                 h.panel_apply(K, native.APPLY_SIGMA | native.APPLY_AUX)
                 t3 = mk()
                 self._steps.append((t0, t1, t3, t3, t1, t2))   # plain schedule: the wait sits between t1 and t2
         tc = mk()
-        pred_l, err_l = h.aux_finish()
-        info = h.factor_info()
+        # The outcome is COLLECTIVE: an error that only this rank sees -- a timed-out cooperative panel step
+        # (ck_factor_info reports it and switches the step off for this handle), an allocation failure, ... -- must not
+        # keep this rank out of the gather below while the others block in it.  It travels in the gathered buffer:
+        # status 1 = "my panel step timed out: sweep again" (every rank then repeats the pass together, as ck_factor
+        # does for one process), status 2 = any other failure (every rank raises).
+        status, local_err = 0, None
+        try:
+            pred_l, err_l = h.aux_finish()
+            info = h.factor_info()
+        except native.NativeError as e:
+            local_err = e
+            status = 1 if "cooperative panel step timed out" in str(e) else 2
+            pred_l, err_l, info = np.zeros(hi - lo), np.zeros(hi - lo), 0
         td = mk()
         self._marks.wait(td)
         ms = self._marks.ms
@@ -516,14 +541,16 @@ class DistributedJoint:
                 tm["bcast_wait_ms"] += ms(st[4], st[5])
                 tm["update_ms"] += ms(st[5], st[2])
         self.timings = tm
-        if self.world == 1:
+        statuses = [status]
+        if not self._comm:
             pred, err = pred_l, err_l
         else:
             dev = self.device if self.device is not None else "cpu"
-            buf = torch.zeros(2 * chunk + 1, dtype=torch.float64, device=dev)
+            buf = torch.zeros(2 * chunk + 2, dtype=torch.float64, device=dev)
             buf[:hi - lo] = torch.from_numpy(pred_l).to(dev)
             buf[chunk:chunk + hi - lo] = torch.from_numpy(err_l).to(dev)
             buf[2 * chunk] = float(info if info != 0 else 2 ** 62)
+            buf[2 * chunk + 1] = float(status)
             allb = [torch.empty_like(buf) for _ in range(self.world)]
             dist.all_gather(allb, buf, group=self.group)
             allb = [b.cpu().numpy() for b in allb]
@@ -532,6 +559,19 @@ class DistributedJoint:
             infos = [int(b[2 * chunk]) for b in allb]
             info = min(infos)
             info = 0 if info >= 2 ** 62 else info
+            statuses = [int(b[2 * chunk + 1]) for b in allb]
+        if max(statuses) >= 2:
+            if local_err is not None and status >= 2:
+                raise local_err
+            bad = [r for r, st in enumerate(statuses) if st >= 2]
+            raise native.NativeError(f"rank(s) {bad} failed in this pass (their own error is raised in their process)")
+        if max(statuses) == 1:
+            # some rank's cooperative panel step timed out; its handle now runs the panel step launch by launch.  Everybody
+            # sweeps again (bounded: a handle reports this at most once -- the step is off afterwards)
+            self._coop_resweeps = getattr(self, "_coop_resweeps", 0) + 1
+            if self._coop_resweeps > self.world + 1:
+                raise native.NativeError("cooperative panel step keeps timing out")
+            return self.predict(i, pcoords)
         if info != 0:
             # every rank sees the same info.  scipy names the failing minor in the CALLER's site order: sweep once more
             # in that order (as ck_factor does for one process); the handle then stays in it

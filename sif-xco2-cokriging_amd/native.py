@@ -63,6 +63,7 @@ _PROTOS = {
     "ck_factor_info": [c_void_p, POINTER(c_int64)],
     "ck_predict_local": [c_void_p, c_int, _dp, c_int64, c_double, c_int, _dp, _dp, POINTER(c_int64), POINTER(c_int64),
                          POINTER(c_int64)],
+    "ck_local_reserve": [c_void_p, c_int64],
     "ck_vario_begin": [c_void_p, _dp, _dp, c_int64, _dp, _dp, c_int64, c_int],
     "ck_vario_extent": [c_void_p, c_double, _dp, _dp, POINTER(c_int64)],
     "ck_vario_bin": [c_void_p, c_double, _dp, c_int, c_int, _dp, POINTER(c_int64)],
@@ -80,6 +81,7 @@ _PROTOS = {
     "ck_debug_gemm_clock": [c_void_p, _dp],
     "ck_debug_stream_overlap": [c_void_p, c_int, c_int64, c_int, _dp],
     "ck_debug_tile_map": [c_int64, c_int, c_int, c_int, POINTER(c_int32), c_int64],
+    "ck_debug_tall_map": [c_int64, c_int, c_int, c_int, POINTER(c_int32), c_int64],
     "ck_debug_run_map": [POINTER(c_int32), c_int, POINTER(c_int32), c_int64],
     "ck_debug_gemm_stamps": [c_void_p, POINTER(c_uint64), c_int64, POINTER(c_int64)],
     "ck_debug_cu_probe": [c_void_p, POINTER(c_uint32), c_int, POINTER(c_uint32)],
@@ -123,7 +125,7 @@ def _preload_hip_runtime():
             pass
 
 
-_RET_INT64 = {"ck_debug_tile_map", "ck_debug_run_map"}
+_RET_INT64 = {"ck_debug_tile_map", "ck_debug_tall_map", "ck_debug_run_map"}
 
 
 def lib():
@@ -181,6 +183,18 @@ def tile_map(nvalid: int, J0: int, Jstep: int, nJ: int):
     out = np.zeros((n, 3), dtype=np.int32)
     if n:
         lib().ck_debug_tile_map(int(nvalid), int(J0), int(Jstep), int(nJ), out.ctypes.data_as(POINTER(c_int32)), n)
+    return out
+
+
+def tall_map(nvalid: int, J0: int, nJ: int, aux_tile_rows: int):
+    """(block column, tile row, tile column, is right-hand-side tile) of every workgroup of one update of the tall matrix
+    [Sigma; c0^T; z^T] (include/cokrige.h: ck_debug_tall_map; host only)."""
+    n = lib().ck_debug_tall_map(int(nvalid), int(J0), int(nJ), int(aux_tile_rows), None, 0)
+    if n < 0:
+        _chk(-1)
+    out = np.zeros((n, 4), dtype=np.int32)
+    if n:
+        lib().ck_debug_tall_map(int(nvalid), int(J0), int(nJ), int(aux_tile_rows), out.ctypes.data_as(POINTER(c_int32)), n)
     return out
 
 
@@ -408,6 +422,10 @@ class Handle:
                                     byref(ne), byref(npd), byref(km)))
         return pred, err, dict(n_empty=ne.value, n_not_pd=npd.value, k_max=km.value)
 
+    def local_reserve(self, nbytes: int = 0):
+        """Pre-size the scratch slab of predict_local (0: the automatic budget) -- include/cokrige.h: ck_local_reserve."""
+        _chk(lib().ck_local_reserve(self._h, int(nbytes)))
+
     # -- empirical variogram ------------------------------------------------------------------------
     def vario_begin(self, coords_i, resid_i, coords_j=None, resid_j=None):
         ci, ri = _f64(coords_i, 2), _f64(resid_i).ravel()
@@ -528,11 +546,11 @@ class Handle:
         return out, grid
 
     def timings(self):
-        out = np.zeros(14)
-        _chk(lib().ck_timings(self._h, _p(out), 14))
+        out = np.zeros(16)
+        _chk(lib().ck_timings(self._h, _p(out), 16))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
                 "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms",
-                "panel_coop_redone", "fused_sweeps_ms"]
+                "panel_coop_redone", "fused_sweeps_ms", "local_alloc_ms", "reserved"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):

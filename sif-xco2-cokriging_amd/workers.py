@@ -102,7 +102,7 @@ def _rank_main(rank, world, device, port, backend, conn, opts):
                             state["h"].close()
                         h = new_handle()
                         r = DistributedJoint(h, rank, world, dist_module=dist, device=dev,
-                                             exchange=opts.get("exchange", "auto") if backend == "nccl" else "broadcast",
+                                             exchange=opts.get("exchange", "broadcast") if backend == "nccl" else "broadcast",
                                              panel_group=opts.get("panel_group", 1)).prepare(m)
                         r.calibrate()
                         state.update(h=h, runner=r, m_cap=m)
@@ -142,7 +142,9 @@ class RankPool:
     """`len(devices)` worker processes, one rank per entry of `devices` (device ordinals; the same ordinal twice =
     two ranks sharing that GPU over gloo)."""
 
-    def __init__(self, devices, backend: str = None, exchange: str = "auto", panel_group=1, start_timeout: float = 600.0):
+    def __init__(self, devices, backend: str = None, exchange: str = "broadcast", panel_group=1, start_timeout: float = 600.0):
+        # exchange: "broadcast" until an 8-GPU run has recorded "sag" / "p2p" in comm_info (ADVICE r03: "auto" would send the
+        # first real multi-GPU call of a notebook through an exchange that has only ever run on gloo); bench.py calibrates
         import torch.multiprocessing as mp
         self.devices = [int(d) for d in devices]
         if not self.devices:
@@ -165,33 +167,57 @@ class RankPool:
         self.last_timings, self.last_comm = {}, {}
 
     # -- plumbing ------------------------------------------------------------------------------------
-    def _collect(self, timeout=None):
-        """One reply per rank; raises if any rank failed or died."""
+    def _collect(self, timeout=None, grace=None):
+        """One reply per rank; raises if any rank failed or died.
+
+        ONE deadline for the whole request (not one per rank), all pipes polled together.  With more than one rank an error
+        on a single rank usually leaves the others inside a collective they will never leave, so the first
+        error starts a short grace period (CK_RANK_GRACE, default 15 s: long enough for errors every rank raises together --
+        a Sigma that is not positive definite -- to arrive from all of them); ranks still silent after it are taken to be
+        stuck and the pool is killed.  A pool in which every rank answered, with errors or not, stays usable."""
+        import time
+        from multiprocessing.connection import wait as conn_wait
         timeout = self.timeout if timeout is None else timeout
-        replies, errors = [], []
-        for r, (c, p) in enumerate(zip(self._conns, self._procs)):
-            waited = 0.0
-            while not c.poll(1.0):
-                waited += 1.0
-                if not p.is_alive():
+        grace = float(os.environ.get("CK_RANK_GRACE", "15")) if grace is None else grace
+        n = len(self._conns)
+        replies, errors, lost = [None] * n, [], False
+        pending = set(range(n))
+        deadline = time.monotonic() + timeout
+        err_deadline = None
+        while pending:
+            ready = conn_wait([self._conns[r] for r in pending], timeout=0.5)
+            for r in sorted(pending):
+                c, p = self._conns[r], self._procs[r]
+                if c in ready:
+                    pending.discard(r)
+                    try:
+                        msg = c.recv()
+                    except (EOFError, OSError):
+                        errors.append(("RankError", f"rank {r} closed its pipe (exit code {p.exitcode})"))
+                        lost = True
+                        continue
+                    if msg[0] == "err":
+                        errors.append((msg[1], msg[2]))
+                    else:
+                        replies[r] = msg[1]
+                elif not p.is_alive():
+                    pending.discard(r)
                     errors.append(("RankError", f"rank {r} died (exit code {p.exitcode})"))
-                    break
-                if waited > timeout:
-                    errors.append(("RankError", f"rank {r} did not answer within {timeout:.0f} s"))
-                    break
-            else:
-                try:
-                    msg = c.recv()
-                except EOFError:
-                    errors.append(("RankError", f"rank {r} closed its pipe"))
-                    continue
-                if msg[0] == "err":
-                    errors.append((msg[1], msg[2]))
-                replies.append(msg[1] if msg[0] == "ok" else None)
-                continue
-            replies.append(None)
+                    lost = True
+            now = time.monotonic()
+            if errors and err_deadline is None:
+                err_deadline = now + grace
+            if pending and err_deadline is not None and now > err_deadline:
+                errors.append(("RankError", f"rank(s) {sorted(pending)} did not answer within {grace:.0f} s of another rank's failure "
+                                            "(stuck in a collective): pool terminated"))
+                lost = True
+                break
+            if pending and now > deadline:
+                errors.append(("RankError", f"rank(s) {sorted(pending)} did not answer within {timeout:.0f} s"))
+                lost = True
+                break
         if errors:
-            if any(e[0] == "RankError" for e in errors):
+            if lost:
                 self._kill()
             name, text = errors[0]
             if name == "LinAlgError":
@@ -209,7 +235,10 @@ class RankPool:
         if not self._procs:
             raise RankError("the rank pool is closed")
         for c in self._conns:
-            c.send(msg)
+            try:
+                c.send(msg)
+            except (BrokenPipeError, OSError):
+                pass            # a rank that is gone: _collect names it
         return self._collect()
 
     def _kill(self):
@@ -240,14 +269,21 @@ class RankPool:
         return self._request("predict_local", int(i), pc, float(max_dist), bool(cv))[0]
 
     def close(self):
+        """Ask the ranks to leave; ranks that do not answer within a few seconds (stuck in a collective after another
+        rank's failure) are terminated -- close() and garbage collection never wait for the request timeout."""
         if not self._procs:
             return
         try:
-            self._request("close")
+            for c in self._conns:
+                try:
+                    c.send(("close",))
+                except (BrokenPipeError, OSError):
+                    pass
+            self._collect(timeout=float(os.environ.get("CK_RANK_CLOSE_TIMEOUT", "10")), grace=3.0)
         except Exception:
             pass
         for p in self._procs:
-            p.join(timeout=30)
+            p.join(timeout=5)
         self._kill()
 
     def __del__(self):

@@ -37,8 +37,30 @@ def _worker(rank, world, port, case, q):
             tok = case.split("_")
             exchange = "p2p" if "p2p" in tok else "sag" if "sag" in tok else "auto" if "auto" in tok else "broadcast"
             group = 3 if "g3" in tok else 2 if "g2" in tok else "auto" if "gauto" in tok else 1
+            if "cooptimeout" in tok or "rankfails" in tok:
+                # ONE rank's handle reports an error that the others do not see (include/cokrige.h: ck_factor_info fails on
+                # the rank whose cooperative panel step timed out, once; "rankfails": some other local failure)
+                from sif_xco2_cokriging_amd.native import NativeError
+                real, state = h.factor_info, {"n": 0}
+
+                def flaky():
+                    state["n"] += 1
+                    if rank == world - 1 and (state["n"] == 1 or "rankfails" in tok):
+                        raise NativeError("cooperative panel step timed out waiting for a pivot block (option panel_fused "
+                                          "bit 4 now off): sweep again" if "cooptimeout" in tok else "hipErrorOutOfMemory")
+                    return real()
+                h.factor_info = flaky
             r = DistributedJoint(h, rank, world, dist_module=dist, lookahead="sequential" not in tok,
-                                 exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
+                                 exchange=exchange, panel_group=group, rehearse_collectives="rehearse" in tok
+                                 ).prepare(len(g["pcoords_A"]))
+            if "rankfails" in tok:
+                from sif_xco2_cokriging_amd.native import NativeError
+                try:
+                    r.predict(1, g["pcoords_A"])
+                    q.put((rank, "no-raise", None, None))
+                except NativeError as e:
+                    q.put((rank, "raised: " + str(e).split("\n")[0], None, None))
+                return
             if exchange == "auto":
                 info = r.calibrate(reps=1, candidates=("broadcast", "sag", "p2p"))
                 assert info["exchange"] in ("broadcast", "sag", "p2p") and r.exchange == info["exchange"]
@@ -121,6 +143,29 @@ def test_joint_predict_two_ranks(world, case):
             assert np.max(np.abs(more[1] ** 2 - g["pred_err_A_0"] ** 2)) < 1e-10
     # every rank returns the same full-length vectors
     assert np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("world,case", [(2, "solve_cooptimeout"), (3, "solve_g3_cooptimeout"), (1, "solve_rehearse"),
+                                        (1, "solve_sag_rehearse_g3"), (1, "solve_p2p_rehearse"), (1, "solve_auto_rehearse")])
+def test_one_ranks_timeout_is_swept_again_by_all_and_world1_rehearses_the_collectives(world, case):
+    """(a) ADVICE r03: a cooperative panel step that timed out on ONE rank used to raise there in front of the result
+    gather while the other ranks blocked in it; the outcome now travels in the gathered buffer and every rank repeats the
+    pass.  (b) rehearse_collectives: a one-rank group issues every collective of the schedules (what a single GPU can run
+    of the nccl path; here on gloo)."""
+    g = load_golden("joint_solve")
+    out = _run(world, case)
+    assert len(out) == world
+    for rank, status, pred, err, *more in out:
+        assert status == "ok"
+        assert np.max(np.abs(pred - g["pred_A_1"])) / np.max(np.abs(g["pred_A_1"])) < 1e-9
+        assert np.max(np.abs(err ** 2 - g["pred_err_A_1"] ** 2)) < 1e-10
+
+
+def test_a_local_failure_on_one_rank_raises_on_every_rank_instead_of_deadlocking():
+    out = _run(3, "solve_rankfails")
+    assert [st for _, st, *_ in out][2] == "raised: hipErrorOutOfMemory"
+    for rank, status, *_ in out[:2]:
+        assert status.startswith("raised: rank(s) [2] failed"), status
 
 
 def test_not_positive_definite_all_ranks_raise():

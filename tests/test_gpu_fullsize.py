@@ -80,3 +80,48 @@ def test_variogram_1M_soundings_properties():
     assert np.array_equal(k2, res[1][3]) and np.array_equal(e2, res[1][1])
     np.testing.assert_allclose(m2, res[1][2], rtol=1e-10)
     h.close()
+
+
+def test_cross_variogram_1M_by_1M_soundings_properties():
+    """BASELINE configs[4] AS WRITTEN: the empirical CROSS-semivariogram (i != j: all n_i n_j pairs,
+    src/fields.py:201-204) of 1 000 000 x 1 000 000 soundings -- 1e12 pairs -- through what the domain offers at that size:
+    the bins partition all pairs, a checksum of all cloud values, culling on / off, permutation of either point set."""
+    from sif_xco2_cokriging_amd import native
+    from sif_xco2_cokriging_amd.variogram import variogram_arrays
+    n = 1_000_000
+    rng = np.random.default_rng(20006)
+    ci = np.column_stack([rng.uniform(22, 58, n), rng.uniform(-125, -65, n)])
+    cj = np.column_stack([rng.uniform(22, 58, n), rng.uniform(-125, -65, n)])
+    vi = rng.standard_normal(n)
+    vj = 0.6 * rng.standard_normal(n) + 0.3
+    h = native.Handle(0)
+    h.set_metric(0)
+    # (1) no cap: every one of the n_i n_j pairs lands in exactly one bin
+    cen, edg, mean, cnt = variogram_arrays(h, ci, vi, cj, vj, False, 1e9, 30)
+    assert int(cnt.sum()) == n * n
+    assert h.vario_stats()["bin_visited_pairs"] >= n * n
+    # sum over all pairs of 0.5 ((a_i - abar) - (b_j - bbar))^2 = 0.5 n_i n_j (var a + var b) exactly (src/fields.py:378-386
+    # centres each field): a checksum of all 1e12 cloud values through the binning
+    np.testing.assert_allclose(float((mean * cnt).sum()), 0.5 * n * n * (vi.var() + vj.var()), rtol=1e-9)
+    np.testing.assert_allclose(mean, 0.5 * (vi.var() + vj.var()), rtol=5e-2)       # independent white noise: flat
+    # (2) the headline case (1 500 km, 30 bins): culling on (Hilbert order) and off (caller's order) see the same pairs
+    res = {}
+    for order in (1, 0):
+        hh = native.Handle(0)
+        hh.set_option("site_order", order)
+        hh.set_metric(0)
+        res[order] = variogram_arrays(hh, ci, vi, cj, vj, False, 1500.0, 30)
+        res[order] += (hh.vario_stats()["bin_visited_pairs"],)
+        hh.close()
+    assert np.array_equal(res[1][3], res[0][3]) and np.array_equal(res[1][1], res[0][1])
+    np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-10)
+    assert res[1][4] < 0.4 * res[0][4] and int(res[1][3].sum()) < n * n
+    # (3) permutation of either point set; (4) swapping the two sets (the cloud value is symmetric in its arguments)
+    pi, pj = rng.permutation(n), rng.permutation(n)
+    c2, e2, m2, k2 = variogram_arrays(h, ci[pi], vi[pi], cj[pj], vj[pj], False, 1500.0, 30)
+    assert np.array_equal(k2, res[1][3]) and np.array_equal(e2, res[1][1])
+    np.testing.assert_allclose(m2, res[1][2], rtol=1e-10)
+    c3, e3, m3, k3 = variogram_arrays(h, cj, vj, ci, vi, False, 1500.0, 30)
+    assert np.array_equal(k3, res[1][3]) and np.array_equal(e3, res[1][1])
+    np.testing.assert_allclose(m3, res[1][2], rtol=1e-10)
+    h.close()

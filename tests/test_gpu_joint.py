@@ -602,10 +602,117 @@ def test_factor_predict_overlapped_matches_the_fixture_and_the_sequence(native, 
         h.factor_predict(0, g[f"pcoords_{tag}"])              # already factored
 
 
+@pytest.mark.parametrize("group", [0, 1, 2, 3, 4, 5, 11, 16])
+@pytest.mark.parametrize("m", [700, 0, 1, 255, 256])
+def test_tall_sweep_many_panels_every_group_size(native, group, m):
+    """ck_factor_predict's default schedule (round 4): ONE sweep over the tall matrix [Sigma; c0^T; z^T] -- the right-hand-side
+    rows as further workgroups of the cooperative panel step and further tiles of every update launch -- at 11 panels
+    (N = 5 200), for group sizes that do and do not divide them (the look-ahead's A / B1 / B2 launches with one, two, three
+    groups left; one group for everything), and for right-hand-side blocks of one and several tile rows: the SAME BITS as
+    ck_factor + ck_predict with that grouping, the factor resident afterwards."""
+    if m != 700 and group not in (0, 3):
+        pytest.skip("the small right-hand-side blocks run with the default and one forced grouping")
+    rng = np.random.default_rng(11)
+    n = 2600
+    coords = [np.column_stack([rng.uniform(25, 49, n), rng.uniform(-124, -67, n)]) for _ in range(2)]
+    values = [rng.standard_normal(n), rng.standard_normal(n)]
+    params = load_golden("joint_solve")["params_A"]
+    pc = np.column_stack([rng.uniform(25, 49, m), rng.uniform(-124, -67, m)])
+    h, p = _assembled(native, params, coords, values, HAV)
+    if group:
+        h.set_option("panel_group", group)      # the sequence with the same grouping = the same summation order
+    assert h.factor() == 0
+    ref = h.predict(1, pc)
+    h2, _ = _assembled(native, params, coords, values, HAV)
+    h2.set_option("fused_group", group)
+    h2.set_option("time_gemm", 1)
+    info, pred, err = h2.factor_predict(1, pc)
+    assert info == 0
+    assert np.array_equal(pred, ref[0]) and np.array_equal(err, ref[1])
+    t = h2.timings()
+    assert t["fused_sweeps_ms"] > 0 and t["panel_coop_redone"] == 0
+    G = group if group else 1                   # automatic: 1 below 40 panels
+    ng = -(-11 // G)
+    launches = sum(min(G, 11 - g * G) - 1 for g in range(ng)) + sum(1 for g in range(ng) for d in (1, 2, 3) if g + d < ng)
+    assert t["syrk_launches"] == launches, (t["syrk_launches"], launches)
+    again = h2.predict(0, pc)                   # on the factor the tall sweep left resident
+    assert np.array_equal(again[0], h.predict(0, pc)[0])
+    h3, _ = _assembled(native, params, coords, values, HAV)
+    h3.set_option("tall_sweep", 0)              # round 3's two overlapped sweeps: still the same bits
+    h3.set_option("fused_group", group)
+    info, p3, e3 = h3.factor_predict(1, pc)
+    assert info == 0 and np.array_equal(p3, ref[0]) and np.array_equal(e3, ref[1])
+
+
+@pytest.mark.parametrize("entry", ["factor", "factor_predict", "factor_predict_two_sweeps"])
+def test_cooperative_panel_step_timeout_is_detected_and_the_factorisation_redone(native, entry):
+    """k_panel_coop's safety net: option coop_inject_panel makes one workgroup of the diagonal block
+    skip its flag store, so the bounded waits of the chunks below it trip, the error word is set, and the host must notice,
+    switch the cooperative step off and repeat the factorisation with one launch per dependency -- for ck_factor and for
+    both forms of ck_factor_predict -- with results equal to the plain schedule's and the event visible in ck_timings."""
+    rng = np.random.default_rng(21)
+    n = 1500
+    coords = [np.column_stack([rng.uniform(25, 49, n), rng.uniform(-124, -67, n)]) for _ in range(2)]
+    values = [rng.standard_normal(n), rng.standard_normal(n)]
+    params = load_golden("joint_solve")["params_A"]
+    pc = np.column_stack([rng.uniform(25, 49, 300), rng.uniform(-124, -67, 300)])
+    href, _ = _assembled(native, params, coords, values, HAV)
+    href.set_option("panel_fused", 2)           # never cooperative
+    assert href.factor() == 0
+    ref = href.predict(0, pc)
+    h, _ = _assembled(native, params, coords, values, HAV)
+    h.set_option("coop_spins", 20000)           # ~20 ms instead of ~2 s per timed-out wait
+    h.set_option("coop_inject_panel", 2)        # panel 2 of 6
+    if entry == "factor":
+        assert h.factor() == 0
+        assert h.timings()["panel_coop_redone"] == 1
+        got = h.predict(0, pc)
+    else:
+        if entry.endswith("two_sweeps"):
+            h.set_option("tall_sweep", 0)
+        info, *got = h.factor_predict(0, pc)
+        assert info == 0
+        assert h.timings()["panel_coop_redone"] == 1
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    # the handle keeps working, without the cooperative step
+    h.assemble_joint()
+    info, p2, e2 = h.factor_predict(0, pc)
+    assert info == 0 and np.array_equal(p2, ref[0]) and h.timings()["panel_coop_redone"] == 0
+
+
+def test_step_wise_driver_sweeps_again_after_a_cooperative_timeout(native):
+    """The same event in the step-wise form every rank of a multi-GPU run executes (distributed.DistributedJoint, world = 1):
+    ck_factor_info reports it, the driver encodes it in the gathered status and repeats the pass."""
+    import torch
+    from sif_xco2_cokriging_amd.distributed import DistributedJoint
+    rng = np.random.default_rng(22)
+    n = 1300
+    coords = [np.column_stack([rng.uniform(25, 49, n), rng.uniform(-124, -67, n)]) for _ in range(2)]
+    values = [rng.standard_normal(n), rng.standard_normal(n)]
+    params = load_golden("joint_solve")["params_A"]
+    pc = np.column_stack([rng.uniform(25, 49, 200), rng.uniform(-124, -67, 200)])
+    href, _ = _assembled(native, params, coords, values, HAV)
+    assert href.factor() == 0
+    ref = href.predict(1, pc)
+    pv = params
+    h = native.Handle(0)
+    h.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+    h.set_metric(HAV)
+    for k in range(2):
+        h.set_data(k, coords[k], values[k])
+    h.set_option("coop_spins", 20000)
+    h.set_option("coop_inject_panel", 1)
+    r = DistributedJoint(h, 0, 1, device=torch.device("cuda", 0)).prepare(len(pc))
+    pred, err = r.predict(1, pc)
+    assert r._coop_resweeps == 1
+    assert rel(pred, ref[0]) < 1e-11 and rel(err, ref[1]) < 1e-11
+
+
 @pytest.mark.parametrize("la", [0, 1])
 @pytest.mark.parametrize("prio,group", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 4)])
 def test_factor_predict_many_panels_every_schedule(native, prio, group, la):
-    """Enough panels for groups, look-ahead boundaries and the last, shorter group (N = 5 200: 11 panels); every stream
+    """Round 3's form (option tall_sweep = 0): factorisation and substitution as two overlapped sweeps.
+    Enough panels for groups, look-ahead boundaries and the last, shorter group (N = 5 200: 11 panels); every stream
     assignment and group size gives the sequence's result."""
     rng = np.random.default_rng(11)
     n = 2600
@@ -617,6 +724,7 @@ def test_factor_predict_many_panels_every_schedule(native, prio, group, la):
     assert h.factor() == 0
     ref = h.predict(1, pc)
     h2, _ = _assembled(native, params, coords, values, HAV)
+    h2.set_option("tall_sweep", 0)
     h2.set_option("fused_prio", prio)
     h2.set_option("fused_group", group)
     h2.set_option("fused_la", la)     # three streams: chain + next group's update / bulk / substitution

@@ -57,11 +57,33 @@ def test_n40000_prediction_vs_exact_entries_and_vendor_solver():
     h.assemble_joint()
     assert h.factor() == 0
     cols = np.linspace(0, len(pc) - 1, 64).astype(int)   # 64 of the 8 833 grid points, spread over the grid
-    got = {}
+    got, full = {}, {}
     for i in (0, 1):
         p, e = h.predict(i, pc)                          # the FULL grid, as the bench does; compared at the sampled points
         got[i] = (p[cols], e[cols])
+        full[i] = (p, e)
     assert h.num_panels()[0] == 79                       # grouped (G = 3) sweeps are the default from 40 panels on
+    # THE PRODUCT SCHEDULE at this size: what Predictor.__call__, smoke() and the bench's timed step
+    # run -- ck_factor_predict with its DEFAULT options: 79 panels, groups of three, one sweep over the tall matrix
+    # [Sigma; c0^T; z^T] with the look-ahead on two streams -- on a fresh handle: the same bits as ck_factor + ck_predict
+    # above on all 8 833 points, hence the same distance to the independent chain below.
+    hp = _handle(pb)
+    hp.assemble_joint()
+    info, pp, pe = hp.factor_predict(0, pc)
+    tp = hp.timings()
+    assert info == 0 and hp.num_panels()[0] == 79 and tp["fused_sweeps_ms"] > 0 and tp["panel_coop_redone"] == 0
+    assert np.array_equal(pp, full[0][0]) and np.array_equal(pe, full[0][1])
+    pp1, pe1 = hp.predict(1, pc)                         # on the factor the product schedule left resident
+    assert np.array_equal(pp1, full[1][0]) and np.array_equal(pe1, full[1][1])
+    # ... and round 3's form of the same call (two overlapped sweeps, three streams) for the record
+    hp.set_option("tall_sweep", 0)
+    hp.assemble_joint()
+    info, pq, pqe = hp.factor_predict(0, pc)
+    assert info == 0 and hp.timings()["fused_sweeps_ms"] > 0
+    assert np.array_equal(pq, full[0][0]) and np.array_equal(pqe, full[0][1])
+    print(f"N = 40 000: ck_factor_predict (defaults: tall sweep, G = 3, look-ahead; {tp['fused_sweeps_ms']:.1f} ms) == "
+          "ck_factor + ck_predict bit for bit on 8 833 points, both processes")
+    hp.close()
     S = _exact_sigma_gpu(h, coords)
     z = torch.from_numpy(np.concatenate(pb["values"])).cuda()
     L = torch.linalg.cholesky(S)                         # :69 cho_factor

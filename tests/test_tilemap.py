@@ -46,6 +46,40 @@ def test_tile_map_covers_the_lower_triangle_exactly_once():
         assert np.array_equal(got, want), (nvalid, J0, Jstep, nJ)
 
 
+def brute_tall(nvalid, J0, nJ, axr):
+    """the triangle tiles of every block column followed by the axr x 4 tiles of the right-hand-side block below it (tile
+    columns inside the identity padding dropped: their update is exactly zero)"""
+    tri = brute(nvalid, J0, 1, nJ)
+    out = []
+    for J in range(J0, J0 + nJ):
+        grp = tri[tri[:, 0] == J]
+        out += [(J, int(tm), int(tn), 0) for _, tm, tn in grp]
+        if len(grp):
+            out += [(J, tm, tn, 1) for tm in range(axr) for tn in range(4) if J * 512 + tn * 128 < nvalid]
+    return np.array(out, dtype=np.int32).reshape(-1, 4)
+
+
+def test_tall_map_appends_the_right_hand_side_tiles_of_every_block_column():
+    """ck_factor_predict's launches over the tall matrix [Sigma; c0^T; z^T] (k_tall_group_d): exactly the tiles of
+    k_syrk_group_d and k_aux_group_d together, once each, column by column."""
+    n = 0
+    for nvalid in (1, 100, 129, 385, 512, 513, 700, 1024, 4600, 9984, 10000, 40000, 40064):
+        nK = (nvalid + 511) // 512
+        for J0 in sorted({0, 1, 2, nK // 2, nK - 2, nK - 1}):
+            if J0 < 0 or J0 >= nK:
+                continue
+            full = nK - J0
+            for nJ in sorted({1, 2, 3, full - 1, full}):
+                if not 1 <= nJ <= full:
+                    continue
+                for axr in (0, 1, 2, 70):
+                    got = native.tall_map(nvalid, J0, nJ, axr)
+                    want = brute_tall(nvalid, J0, nJ, axr)
+                    assert got.shape == want.shape and np.array_equal(got, want), (nvalid, J0, nJ, axr)
+                    n += 1
+    assert n > 400
+
+
 def test_tile_map_rejects_a_first_column_inside_the_padding():
     with pytest.raises(native.NativeError):
         native.tile_map(1000, 2, 1, 1)
