@@ -127,11 +127,11 @@ def measured_traffic():
     runs of this very command, KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
     streams).  A committed measurement of the same workload, NOT a live counter of this run -- `traffic_source` in the
     bench line says which file it came from; (None, None) if absent."""
-    for name in ("r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json",):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
-                return json.load(open(p)).get("k_syrk_group_bytes_per_launch"), f"profiles/{name} (committed rocprofv3 --pmc pass of this command, not a live counter of this run)"
+                return json.load(open(p)).get("k_tall_group_bytes_per_launch"), f"profiles/{name} (committed rocprofv3 --pmc pass of this command, not a live counter of this run)"
             except Exception:
                 return None, None
     return None, None
@@ -167,6 +167,8 @@ def main():
                          "or 1 (unit square, Euclidean, n_obs = 5000, 100 x 100 grid -- a side measurement)")
     ap.add_argument("--params", default="A")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the secondary block: one pass of BASELINE configs[3] (n_obs = 50 000 per process, N = 100 000) on the same ranks")
     ap.add_argument("--sweeps", default="overlapped", choices=["overlapped", "sequential"],
                     help="single GPU: the timed step's factorisation and substitution as two overlapped sweeps (ck_factor_predict, "
                          "the product path, default) or one after the other (ck_factor, ck_predict: what the profiling scripts "
@@ -265,6 +267,7 @@ def main():
 
         def step():
             return runner.predict(0, pb["pcoords"])
+        ex_final, G_final, comm_info, tune_info = runner.exchange, runner.G, runner.comm_info, runner.tune_info
 
     for _ in range(args.warmup):
         step()
@@ -290,20 +293,26 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     tim_fused = tim
     seq_ms = None
+    result_check = None
     if world == 1 and args.sweeps == "sequential":
         seq_ms = ms_per_step
     elif world == 1:
-        # per-kernel measurements: sequential passes of the same workload, outside the timed region
+        # stage measurements: sequential passes of the same workload, outside the timed region -- and the check that the
+        # product schedule of the timed steps (one sweep over the tall matrix, two streams) gives the sequence's BITS
         n_seq = max(1, min(args.steps, 3))
         step_sequential()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tim = []
         for _ in range(n_seq):
-            step_sequential()
+            pred_s, err_s = step_sequential()
             tim.append(h.timings())
         torch.cuda.synchronize()
         seq_ms = (time.perf_counter() - t0) / n_seq * 1e3
+        result_check = {"timed_steps_equal_sequential_passes": bool(np.array_equal(pred, pred_s) and np.array_equal(err, err_s)),
+                        "max_abs_diff": float(max(np.max(np.abs(pred - pred_s)), np.max(np.abs(err - err_s)))),
+                        "what": "(pred, pred_err) of the last timed step (ck_factor_predict, the product schedule) against the last "
+                                "sequential pass (ck_factor, ck_predict) on all grid points; the run fails if they differ"}
     per_rank = None
     if dist is not None:
         # every rank's own breakdown of a step (HIP events on its stream, mean over the timed steps)
@@ -313,6 +322,74 @@ def main():
         dist.all_gather(allr, mine)
         per_rank = [dict(zip(keys, [round(float(x), 3) for x in t.cpu().tolist()])) for t in allr]
 
+    # ---- secondary block: BASELINE configs[3] (n_obs = 50 000 per process, N = 100 000) on the same ranks, one timed pass ----
+    config3 = None
+    want_c3 = (not args.no_config3 and args.config == 2 and n == 20000
+               and os.environ.get("CK_BENCH_CONFIG3", "1" if (world == 1 or backend == "nccl") else "0") == "1")
+    if want_c3:
+        try:
+            pb3 = synth.conus_problem(50000, seed=20004, params=params)
+            m3 = len(pb3["pcoords"])
+            if world == 1:
+                h.close()          # its 10 GB are not needed any more; N = 100 000 takes 40 + 7 GB
+            h3 = native.Handle(local_rank)
+            h3.set_stream(torch.cuda.current_stream().cuda_stream)
+            h3.set_model(2, pv[0:2], pv[2:5], pv[5:8], pv[8:10], pv[10])
+            h3.set_metric(pb3["metric"])
+            for k in range(2):
+                h3.set_data(k, pb3["coords"][k], pb3["values"][k])
+            if world == 1:
+                def step3():
+                    h3.assemble_joint()
+                    info3, p3, e3 = h3.factor_predict(0, pb3["pcoords"])
+                    if info3 != 0:
+                        raise RuntimeError(f"configs[3]: Sigma not positive definite at minor {info3}")
+                    return p3, e3
+            else:
+                runner.h = None
+                del runner
+                h.close()
+                torch.cuda.empty_cache()
+                r3 = distributed.DistributedJoint(h3, rank, world, dist_module=dist, device=torch.device("cuda", local_rank),
+                                                  exchange=ex_final, panel_group=G_final)
+                r3.prepare(m_total=m3)
+
+                def step3():
+                    return r3.predict(0, pb3["pcoords"])
+            step3()                # untimed: first use (allocations, tables)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            p3, e3 = step3()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            dt3 = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt3], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt3 = float(t.item())
+            N3 = 100000
+            t3 = h3.timings()
+            config3 = {"workload": f"configs[3]: n_obs=50000/process (N={N3}), 0.05-degree CONUS lattice, haversine, {m3}-point grid, "
+                                   f"Matern set {args.params}, block-column-cyclic x{world}",
+                       "ms_per_step": dt3 * 1e3, "grid_points_per_s": m3 / dt3, "steps": 1, "warmup": 1,
+                       "frac_of_mfma_peak_whole_step": (N3 ** 3 / 3 + N3 ** 2 * m3) / dt3 / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                       "finite": bool(np.all(np.isfinite(p3)) and np.all(np.isfinite(e3))),
+                       "assemble_sigma_ms": t3["assemble_sigma_ms"], "assemble_c0_ms": t3["assemble_aux_ms"]}
+            if world > 1:
+                config3["rank0"] = dict(r3.timings)
+                config3["exchange"], config3["panel_group"] = r3.exchange, r3.G
+            h3.close()
+        except Exception as e:   # noqa: BLE001 -- a secondary block never costs the run its headline line
+            config3 = {"error": f"{type(e).__name__}: {e}"}
+
+    if dist is not None:
+        # nothing below needs the other ranks: they leave; rank 0 times the CPU baseline and prints the line
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank == 0:
         out = {
             "metric": "cokriging grid-points/s at n_obs=20k bivariate",
@@ -335,96 +412,123 @@ def main():
                                     f"Matern set {args.params}"),
                        "n_obs": n, "N": N, "m": m, "params": pv, "partition": f"block-column-cyclic x{world}"},
         }
-        if per_rank is not None:
-            nK = -(-N // 512)
+        nK = -(-N // 512)
+        Npad = nK * 512
+        cov_bytes = 8.0 * (N * (N + 1) / 2)
+        k2_bytes = 8.0 * N * m
+
+        def hbm(b, ms):
+            return {"GB": b / 1e9, "ms": ms, "GBs": b / (ms / 1e3) / 1e9, "frac_of_hbm_peak": b / (ms / 1e3) / 1e9 / PEAK_HBM_GBS}
+        if world > 1:
             out["per_rank"] = per_rank
             names = {"broadcast": "panel broadcast", "sag": "panel scatter + in-place all-gather (two collectives)",
                      "p2p": "panel scatter + point-to-point all-gather (batch_isend_irecv)"}
-            out["comm"] = {"collective": names.get(runner.exchange, runner.exchange) + f" over {backend}, one per 512-column panel, look-ahead kept",
-                           "exchange": runner.exchange, "exchange_calibration": runner.comm_info,
-                           "panel_group": runner.G, "panel_group_tuning": runner.tune_info, "tuning_error": tuning_error,
+            out["comm"] = {"collective": names.get(ex_final, ex_final) + f" over {backend}, one per 512-column panel, look-ahead kept",
+                           "exchange": ex_final, "exchange_calibration": comm_info,
+                           "panel_group": G_final, "panel_group_tuning": tune_info, "tuning_error": tuning_error,
                            "panels": nK, "bytes_received_per_rank_per_step": int(sum((nK * 512 - K * 512) * 512 * 8 + 8 * 64 * 64 * 8
                                                                                      for K in range(nK) if K % world != 0)),
                            "note": "bcast_wait_ms = time the rank's stream waited for a panel after its own updates were done "
                                    "(exposed communication); panel_ms / update_ms = panel steps / trailing + right-hand-side updates"}
-        if world > 1 and tim[-1]["syrk_launches"] > 0:
             # rank 0's share of the trailing updates: block column J (owned if J % world == 0) receives J panels
-            nK = -(-N // 512)
-            Npad = nK * 512
             flops = sum(J * ((Npad - J * 512) * 512 - 512 * 511 / 2) * 2 * 512 for J in range(0, nK, world))
             tl = tim[-1]
             syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
             out["roofline"] = {
-                "kernel": "k_syrk_group_d on rank 0 (one panel per launch in the multi-GPU form: K = 512, the owned block columns)",
-                "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "kernel": "k_syrk_group_d on rank 0 (the multi-GPU form: K = 512 G, the owned block columns)",
+                "bound": "mfma", "achieved": flops / syrk_s / 1e12 if syrk_s > 0 else None, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS if syrk_s > 0 else None, "traffic": None,
+                "traffic_source": "not measured: the PMC passes (profiles/r04_traffic.json) are of the single-GPU command; a launch of the "
+                                  "multi-GPU form covers this rank's block columns only",
                 "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
                 "algorithmic_flops_per_step": flops,
+                "measured_on": "the timed steps: HIP events around every Sigma trailing-update launch of rank 0 on its stream",
             }
-        if world == 1:
-            tl = tim[-1]
-            flops = trailing_update_flops(N)
-            syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
-            # the PMC passes are of the headline workload only
-            traffic, traffic_source = measured_traffic() if (args.config == 2 and n == 20000) else (None, None)
-            out["roofline"] = {
-                "kernel": "k_syrk_group_d (Cholesky trailing update over 3-panel groups, v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging)",
-                "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_source,
-                "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
-                "algorithmic_flops_per_step": flops,
-                "measured_on": "the timed steps (--sweeps sequential)" if args.sweeps == "sequential" else
-                               (f"{len(tim)} sequential passes of the same workload in this run, behind the timed region (HIP events "
-                                "around every launch of the kernel on its stream; ms_per_step of those passes: "
-                                f"{seq_ms:.1f}): in the timed steps the factorisation and the substitution run as two overlapped "
-                                "sweeps on two streams, where a launch's duration includes the other sweep's share of the chip"),
-                # the timed steps themselves: both GEMM kernels (the same gemm_tile_d) against the span of the two sweeps
-                "overlapped": None if (args.sweeps == "sequential" or tim_fused[-1]["fused_sweeps_ms"] <= 0) else {
-                    "what": "k_syrk_group_d + k_aux_group_d in the timed steps: (N^3/3 + N^2 m) flop / span of the two overlapped sweeps",
-                    "sweeps_ms": float(np.mean([t["fused_sweeps_ms"] for t in tim_fused])),
-                    "achieved": (trailing_update_flops(N) + aux_update_flops(N, m))
-                                / (np.mean([t["fused_sweeps_ms"] for t in tim_fused]) / 1e3) / 1e12,
-                    "frac": (trailing_update_flops(N) + aux_update_flops(N, m))
-                            / (np.mean([t["fused_sweeps_ms"] for t in tim_fused]) / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                },
-            }
-            aux_s = np.mean([t["aux_gemm_ms"] for t in tim]) / 1e3
-            cov_bytes = 8.0 * (N * (N + 1) / 2)
-            # SURVEY section 8(d): covariance assembly = K1 (Sigma, lower triangle) + K2 (c0^T rows), algorithmic bytes
-            # 8 [N (N + 1) / 2 + N m]; stage timers = HIP events around the device work of each (mean over the timed steps)
+            # rank 0's covariance assembly: its owned block columns of Sigma + its shard of the c0^T rows
+            own_bytes = 8.0 * sum(max((N - K * 512) * 512 - 512 * 511 / 2, 0.0) for K in range(0, nK, world))
+            chunk = -(-m // world)
             k1_ms = float(np.mean([t["assemble_sigma_ms"] for t in tim]))
             k2_ms = float(np.mean([t["assemble_aux_ms"] for t in tim]))
-            k2_bytes = 8.0 * N * m
-
-            def hbm(b, ms):
-                return {"GB": b / 1e9, "ms": ms, "GBs": b / (ms / 1e3) / 1e9, "frac_of_hbm_peak": b / (ms / 1e3) / 1e9 / PEAK_HBM_GBS}
+            out["stages"] = {"rank0": {k: float(np.mean([t.get(k, 0.0) for t in rank_tim])) for k in ("assemble_ms", "panel_ms", "update_ms", "bcast_wait_ms", "finish_ms")},
+                             "cov_assembly": {"K1_sigma_rank0": hbm(own_bytes, k1_ms), "K2_c0_rank0": hbm(8.0 * N * chunk, k2_ms),
+                                              "combined_rank0": hbm(own_bytes + 8.0 * N * chunk, k1_ms + k2_ms),
+                                              "definition": "rank 0's share of SURVEY 8(d)'s bytes (its block columns of the lower triangle, "
+                                                            "its shard of the c0 rows) over its own K1 + K2 device time"},
+                             "whole_step_frac_of_mfma_peak_x_gpus": (N ** 3 / 3 + N ** 2 * m) / (ms_per_step / 1e3) / 1e12 / (PEAK_F64_MFMA_TFLOPS * world)}
+        else:
+            tl = tim[-1]
+            tf = tim_fused[-1]
+            tall = args.sweeps != "sequential" and tf["fused_sweeps_ms"] > 0 and tf["syrk_launches"] > 0
+            # the PMC passes are of the headline workload only
+            traffic, traffic_source = measured_traffic() if (args.config == 2 and n == 20000) else (None, None)
+            fl_all = trailing_update_flops(N) + aux_update_flops(N, m)
+            if tall:
+                # the dominant kernel of the timed steps is k_tall_group_d: every update of the tall matrix [Sigma; c0^T; z^T]
+                span_s = float(np.mean([t["fused_sweeps_ms"] for t in tim_fused])) / 1e3
+                sum_ms = float(np.mean([t["syrk_ms"] for t in tim_fused]))
+                nl = tf["syrk_launches"]
+                out["roofline"] = {
+                    "kernel": "k_tall_group_d (every trailing update of the tall matrix [Sigma; c0^T; z^T]: Cholesky AND forward substitution, "
+                              "v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging, K = 512 x group)",
+                    "bound": "mfma", "achieved": fl_all / span_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl_all / span_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "launches_per_step": nl, "avg_launch_ms": sum_ms / max(nl, 1), "sum_launch_ms": sum_ms, "span_ms": span_s * 1e3,
+                    "algorithmic_flops_per_step": fl_all,
+                    "measured_on": "the timed steps themselves: the kernel's algorithmic flops (N^3/3 + N^2 m: all its launches of a step) "
+                                   "over the span of the sweep that issues them (HIP events on the launching streams, first launch to "
+                                   "last) -- a lower bound on the kernel, the span also holds the panel chain and every fill / drain.  "
+                                   "Its launches run on two streams and overlap each other (look-ahead), so sum_launch_ms (HIP events "
+                                   "around every launch on its own stream; avg_launch_ms = sum / launches is what rocprofv3's kernel "
+                                   "stats average) exceeds span_ms",
+                }
+            else:
+                flops = trailing_update_flops(N)
+                syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
+                out["roofline"] = {
+                    "kernel": "k_syrk_group_d (Cholesky trailing update over 3-panel groups, v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging)",
+                    "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                    "traffic": None, "traffic_source": None,
+                    "launches_per_step": tl["syrk_launches"], "avg_launch_ms": tl["syrk_ms"] / max(tl["syrk_launches"], 1),
+                    "algorithmic_flops_per_step": flops,
+                    "measured_on": "the timed steps (--sweeps sequential)" if args.sweeps == "sequential" else
+                                   f"{len(tim)} sequential passes behind the timed region (ms_per_step of those passes: {seq_ms:.1f})",
+                }
+            syrk_seq_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
+            aux_s = np.mean([t["aux_gemm_ms"] for t in tim]) / 1e3
+            # SURVEY section 8(d): covariance assembly = K1 (Sigma, lower triangle) + K2 (c0^T rows), algorithmic bytes
+            # 8 [N (N + 1) / 2 + N m]; stage timers = HIP events around the device work of each (mean over the TIMED steps)
+            k1_ms = float(np.mean([t["assemble_sigma_ms"] for t in tim_fused]))
+            k2_ms = float(np.mean([t["assemble_aux_ms"] for t in tim_fused]))
             cov_assembly = {"K1_sigma": hbm(cov_bytes, k1_ms), "K2_c0": hbm(k2_bytes, k2_ms),
                             "combined": hbm(cov_bytes + k2_bytes, k1_ms + k2_ms),
-                            "definition": "SURVEY 8(d): 8 [N (N + 1) / 2 + N m] algorithmic bytes over K1 + K2"}
-            tf = tim_fused[-1]
+                            "definition": "SURVEY 8(d): 8 [N (N + 1) / 2 + N m] algorithmic bytes over K1 + K2, HIP events around the device "
+                                          "work of each, mean over the timed steps"}
+            out["result_check"] = result_check
             out["stages"] = {
                 "timed_steps": None if args.sweeps == "sequential" else
                                {"assemble_sigma_ms": tf["assemble_sigma_ms"], "assemble_c0_ms": tf["assemble_aux_ms"],
-                                "sweeps_overlapped_ms": tf["fused_sweeps_ms"] if tf["fused_sweeps_ms"] > 0 else None,
-                                "sweeps": "overlapped (ck_factor_predict)" if tf["fused_sweeps_ms"] > 0 else
+                                "sweep_ms": tf["fused_sweeps_ms"] if tf["fused_sweeps_ms"] > 0 else None,
+                                "sweeps": ("ONE sweep over the tall matrix [Sigma; c0^T; z^T] (ck_factor_predict, option tall_sweep)" if tall else
+                                           "two overlapped sweeps (ck_factor_predict)") if tf["fused_sweeps_ms"] > 0 else
                                           "sequential inside ck_factor_predict (more than 128 panels: the library's automatic rule)",
-                                "factorisation_span_ms": tf["factor_ms"],
+                                "chain_end_ms": tf["factor_ms"],
                                 "reduce_ms": tf["reduce_ms"]},
                 "sequential_passes_ms_per_step": seq_ms,
-                "note": "the entries below are from the sequential passes (ck_factor, then ck_predict)",
-                "assemble_sigma_ms": tl["assemble_sigma_ms"], "factor_ms": tl["factor_ms"],
-                "assemble_c0_ms": tl["assemble_aux_ms"], "solve_ms": tl["solve_ms"], "reduce_ms": tl["reduce_ms"],
+                "note": "factor_ms .. solve_gemm_tflops below are from the sequential passes (ck_factor, then ck_predict: k_syrk_group_d / "
+                        "k_aux_group_d, each with the chip to itself)",
+                "factor_ms": tl["factor_ms"], "solve_ms": tl["solve_ms"], "reduce_ms": tl["reduce_ms"],
                 "cholesky_tflops": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12,
                 "cholesky_frac_of_mfma_peak": (N ** 3 / 3) / (tl["factor_ms"] / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                "syrk_frac_of_mfma_peak_sequential": trailing_update_flops(N) / syrk_seq_s / 1e12 / PEAK_F64_MFMA_TFLOPS if syrk_seq_s > 0 else None,
                 "solve_gemm_tflops": aux_update_flops(N, m) / aux_s / 1e12 if aux_s > 0 else None,
                 "cov_assembly": cov_assembly,
                 "cov_assembly_GBs": cov_assembly["combined"]["GBs"],
                 "cov_assembly_frac_of_hbm_peak": cov_assembly["combined"]["frac_of_hbm_peak"],
                 # 14 FP64 operations per tabulated entry (3 sub, mul, 2 fma: squared chord;
                 # sub: offset from the interval centre; 7 fma: Horner) against the 78.6 TF vector peak
-                "cov_assembly_frac_of_fp64_valu_peak": 14.0 * (N * (N + 1) / 2) / (tl["assemble_sigma_ms"] / 1e3) / 1e12
-                                                       / PEAK_F64_MFMA_TFLOPS,
+                "cov_assembly_frac_of_fp64_valu_peak": 14.0 * (N * (N + 1) / 2) / (k1_ms / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                 # factor reused: grid-points/s of one more ck_predict on the resident L (K2 + K4 + reduce)
                 "amortised_grid_points_per_s": m / ((tl["assemble_aux_ms"] + tl["solve_ms"] + tl["reduce_ms"]) / 1e3),
             }
@@ -447,11 +551,13 @@ def main():
                 h2.close()
                 out["pcie_inclusive"] = {"ms": dtc * 1e3, "grid_points_per_s": m / dtc,
                                          "what": "one cold pass, host arrays -> host results, new handle (not the headline value)"}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(N, m)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        if config3 is not None:
+            out["config3"] = config3
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, m)
+        print(json.dumps(out), flush=True)
+        if result_check is not None and not result_check["timed_steps_equal_sequential_passes"]:
+            raise SystemExit("bench.py: the timed steps' results differ from the sequential passes' (result_check)")
 
 
 if __name__ == "__main__":

