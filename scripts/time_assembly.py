@@ -18,10 +18,11 @@ for it in range(12):
     ts.append(h.timings()["assemble_sigma_ms"])
     h.aux_begin(0, pb["pcoords"])
     ta.append(h.timings()["assemble_aux_ms"])
+print("table errors, gate 2e-13:", [(h.table_info(b)["enabled"], f"{h.table_info(b)['max_rel_err']:.2e}") for b in range(3)])
 N, m = 2 * n, len(pb["pcoords"])
 t1, t2 = np.median(ts[2:]), np.median(ta[2:])
 b1, b2 = 8 * N * (N + 1) / 2, 8 * N * m
 print("assemble_sigma_ms", " ".join(f"{t:.3f}" for t in ts), "| median", f"{t1:.3f}", "ms ->", f"{b1 / t1 / 1e9:.2f} TB/s")
 print("assemble_aux_ms  ", " ".join(f"{t:.3f}" for t in ta), "| median", f"{t2:.3f}", "ms ->", f"{b2 / t2 / 1e9:.2f} TB/s",
-      "(the interval includes the upload of the prediction coordinates and k_prep_sites)")
+      "(device work of K2: round 4 one launch + the exact pass)")
 print(f"K1 + K2: {(b1 + b2) / 1e9:.2f} GB in {t1 + t2:.3f} ms -> {(b1 + b2) / (t1 + t2) / 1e9:.2f} TB/s = {(b1 + b2) / (t1 + t2) / 1e9 / 8:.3f} of 8 TB/s")

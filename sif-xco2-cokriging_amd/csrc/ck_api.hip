@@ -105,7 +105,8 @@ struct ck_handle {
     double** d_coefptr = nullptr;
     bool tables_built = false;
     bool exact_cov = false;             // option "exact_cov": bypass the tables
-    CkWorklist wl = {nullptr, nullptr, 0};   // entries deferred by the table kernels
+    CkWorklist wl = {nullptr, nullptr, 0, nullptr};   // entries deferred by the table kernels
+    unsigned* wl_counts = nullptr;           // its two counters (used alternately: next_worklist)
     int64_t fallback_total = 0;
     std::vector<double*> sig;    // per panel; nullptr if not owned
     double** d_sigptr = nullptr;
@@ -296,7 +297,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     if (h->local_slab) (void)hipFree(h->local_slab);
     if (h->d_panel_of) (void)hipFree(h->d_panel_of);
     if (h->wl.items) (void)hipFree(h->wl.items);
-    if (h->wl.count) (void)hipFree(h->wl.count);
+    if (h->wl_counts) (void)hipFree(h->wl_counts);
     if (h->d_tabs) (void)hipFree(h->d_tabs);
     if (h->d_coefptr) (void)hipFree(h->d_coefptr);
     for (int b = 0; b < 3; ++b)
@@ -410,8 +411,10 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     if (!h->wl.items) {
         h->wl.cap = 1u << 22;   // 4 M deferred entries (32 MB); beyond that the assembly re-runs exactly
         HIPCHK(hipMalloc((void**)&h->wl.items, (size_t)h->wl.cap * sizeof(int2)));
-        HIPCHK(hipMalloc((void**)&h->wl.count, sizeof(unsigned)));
-        HIPCHK(hipMemset(h->wl.count, 0, sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&h->wl_counts, 2 * sizeof(unsigned)));   // used alternately: see CkWorklist
+        HIPCHK(hipMemset(h->wl_counts, 0, 2 * sizeof(unsigned)));
+        h->wl.count = h->wl_counts;
+        h->wl.reset = h->wl_counts + 1;
     }
     const int ND = CK_TAB_DEG + 1;
     if (!h->d_tabs) {
@@ -692,6 +695,14 @@ static bool tables_usable(const ck_handle* h) {
         if (!h->tab[b].enabled) return false;
     return true;
 }
+// The worklist of the next table-path assembly: its counter is zero already -- the exact pass of the previous assembly
+// (k_assemble_fix) zeroed it, or the allocation did -- and ITS exact pass will zero the other one.  No memset launch.
+static void next_worklist(ck_handle* h) {
+    unsigned* cur = h->wl.reset;
+    h->wl.reset = h->wl.count;
+    h->wl.count = cur;
+}
+
 // internal (padded-order) 1-based index -> index in the caller's stacked order
 static int64_t external_index(const ck_handle* h, int64_t g) { return g > h->n0p ? g - (h->n0p - h->n[0]) : g; }
 
@@ -699,12 +710,11 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
     CHKH(h);
     if (ensure_layout(h)) return -1;
 
-    HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     bool fast_done = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
-        if (attempt) HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        if (fast) next_worklist(h);   // a zeroed counter, without a memset launch in front of the assembly
         {
             CkPanelMap pm{h->d_tile0, h->d_panel_of, h->d_sigptr, h->n_owned, nullptr, 0};
             ck_launch_assemble_sigma(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0, h->su,
@@ -1476,12 +1486,17 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
     // timed like ck_assemble_joint: the device work of K2 (site transform, table kernel, exact pass) -- not the upload of the
     // prediction coordinates in front of it nor the host round trip for the worklist count behind it
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
+    // table path: ONE launch -- the assembly transforms the prediction sites itself (every strip its 64 rows; the strips of
+    // block column 0 store p0 / pu for the exact pass and the later users) and starts on a counter the previous exact pass
+    // zeroed.  Round 3 had k_prep_sites, a memset, the assembly and the exact pass: the gaps between the four were a tenth of
+    // the stage.  The exact path (no tables) keeps the separate transform.
+    const bool fold = tables_usable(h);
+    if (!fold) ck_launch_prep_sites(h->stream, h->d_pcoords, mpad, h->metric, h->p0, h->p1, h->p2, h->pu);
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
-        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        if (fast) next_worklist(h);
         ck_launch_assemble_aux(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i, h->p0, h->pu, m,
-                               mpad, h->s0, h->su, h->z, layout_of(h), h->nK, h->aux, h->wl);
+                               mpad, h->s0, h->su, h->z, layout_of(h), h->nK, h->aux, h->wl, fast && fold ? h->d_pcoords : nullptr);
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, true, h->d_blk, h->metric, i, h->p0, mpad, h->s0, layout_of(h), h->wl,
                                h->d_sigptr, h->aux);
@@ -1695,7 +1710,7 @@ extern "C" int ck_verify_model(ck_handle* h, int64_t* info) {
     const CkLayout L{m, Mp, Mp, Mp};
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
-        HIPCHK(hipMemsetAsync(h->wl.count, 0, sizeof(unsigned), h->stream));
+        if (fast) next_worklist(h);
         CkPanelMap pm{h->d_sch_tile0, h->d_sch_panel_of, h->d_sch_ptr, nJ, nullptr, 0};
         ck_launch_assemble_sigma(h->stream, fast, h->d_sch_blk, h->d_sch_tabs, h->d_sch_coefptr, h->metric, h->sch_c,
                                  h->sch_u, L, pm, h->sch_tiles, h->wl);

@@ -14,31 +14,40 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // per-site transform -------------------------------------------------------------------
 // c0/c1/c2: (lat_rad, lon_rad, cos lat) | (x, y, 0) for the exact distance formulas;
 // u (optional, 3 x n SoA): unit vector on the sphere | (x, y, 0) -- the chord vectors of the table path.
+// one site: (a, b) = the caller's coordinates -> c = exact-formula form, v = chord vector
+__device__ __forceinline__ void prep_site(int metric, double a, double b, double (&c)[3], double (&v)[3]) {
+    if (metric == CK_METRIC_HAVERSINE) {
+        const double lat = a * CK_DEG2RAD, lon = b * CK_DEG2RAD;   // numpy.radians (fields.py:334-335)
+        const double cl = cos(lat);
+        c[0] = lat;
+        c[1] = lon;
+        c[2] = cl;
+        v[0] = cl * cos(lon);
+        v[1] = cl * sin(lon);
+        v[2] = sin(lat);
+    } else {
+        c[0] = a;
+        c[1] = b;
+        c[2] = 0.0;
+        v[0] = a;
+        v[1] = b;
+        v[2] = 0.0;
+    }
+}
+
 __global__ void k_prep_sites(const double* __restrict__ coords, long n, int metric, double* __restrict__ c0,
                              double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ u) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double a = coords[2 * i], b = coords[2 * i + 1];
-    if (metric == CK_METRIC_HAVERSINE) {
-        const double lat = a * CK_DEG2RAD, lon = b * CK_DEG2RAD;   // numpy.radians (fields.py:334-335)
-        const double cl = cos(lat);
-        c0[i] = lat;
-        c1[i] = lon;
-        c2[i] = cl;
-        if (u) {
-            u[i] = cl * cos(lon);
-            u[n + i] = cl * sin(lon);
-            u[2 * n + i] = sin(lat);
-        }
-    } else {
-        c0[i] = a;
-        c1[i] = b;
-        c2[i] = 0.0;
-        if (u) {
-            u[i] = a;
-            u[n + i] = b;
-            u[2 * n + i] = 0.0;
-        }
+    double c[3], v[3];
+    prep_site(metric, coords[2 * i], coords[2 * i + 1], c, v);
+    c0[i] = c[0];
+    c1[i] = c[1];
+    c2[i] = c[2];
+    if (u) {
+        u[i] = v[0];
+        u[n + i] = v[1];
+        u[2 * n + i] = v[2];
     }
 }
 
@@ -244,8 +253,12 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
                                                                  const double* const* __restrict__ coefs, int metric,
                                                                  int i_pred, CkSiteRef R, long m, CkSiteRef S,
                                                                  const double* __restrict__ z, CkLayout L,
-                                                                 CkPanelMap pm, CkWorklist wl) {
+                                                                 CkPanelMap pm, CkWorklist wl,
+                                                                 const double* __restrict__ raw = nullptr, long mpad = 0,
+                                                                 double* __restrict__ pc_out = nullptr,
+                                                                 double* __restrict__ pu_out = nullptr) {
     __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_STRIDE : 1];
+    __shared__ double srow[(FAST && AUX) ? 3 * 64 : 1];   // chord vectors of this strip's 64 rows (raw != nullptr)
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
     // blockIdx.x enumerates the 64-row tiles of ALL panels of this launch; a workgroup walks the
     // eight 64 x 64 sub-tiles of its 64 x 512 strip
@@ -275,12 +288,41 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
     const bool row_pad = AUX ? (rt + 64 > m) : range_has_padding(L, rt);
     const int zrel = AUX ? (int)(m - rt) - ty : 0;   // this thread's row a is r = m + (16 a - zrel)
     double ru0[4], ru1[4], ru2[4];   // table path: chord vectors of this thread's four rows
+    if (FAST && AUX && raw) {
+        // The prediction sites arrive untransformed (round 4): one wave transforms the strip's 64 rows -- the arithmetic of
+        // k_prep_sites, the same bits -- instead of the whole launch waiting for a transform launch in front of it; the strips of
+        // block column 0 also store the result for the later users (exact pass, _verify_model, further sweeps).
+        if (t < 64) {
+            const long r = rt + t;
+            double c[3], v[3];
+            prep_site(metric, raw[2 * r], raw[2 * r + 1], c, v);
+            srow[t] = v[0];
+            srow[64 + t] = v[1];
+            srow[128 + t] = v[2];
+            if (col0 == 0) {
+                pc_out[r] = c[0];
+                pc_out[mpad + r] = c[1];
+                pc_out[2 * mpad + r] = c[2];
+                pu_out[r] = v[0];
+                pu_out[mpad + r] = v[1];
+                pu_out[2 * mpad + r] = v[2];
+            }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const long r = rt + ty + 16 * a;
-        ru0[a] = FAST ? R.u0[r] : 0.0;
-        ru1[a] = FAST ? R.u1[r] : 0.0;
-        ru2[a] = FAST ? R.u2[r] : 0.0;
+        for (int a = 0; a < 4; ++a) {
+            ru0[a] = srow[ty + 16 * a];
+            ru1[a] = srow[64 + ty + 16 * a];
+            ru2[a] = srow[128 + ty + 16 * a];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long r = rt + ty + 16 * a;
+            ru0[a] = FAST ? R.u0[r] : 0.0;
+            ru1[a] = FAST ? R.u1[r] : 0.0;
+            ru2[a] = FAST ? R.u2[r] : 0.0;
+        }
     }
     int loaded = -1, tbase = 0;
     unsigned tn = 1;
@@ -322,6 +364,7 @@ __global__ __launch_bounds__(256) void k_assemble_fix(const CkMatern* __restrict
                                                        double* const* __restrict__ sigptr, double* __restrict__ aux,
                                                        long mpad) {
     const unsigned n = *wl.count < wl.cap ? *wl.count : wl.cap;
+    if (wl.reset && blockIdx.x == 0 && threadIdx.x == 0) *wl.reset = 0u;   // the next assembly's counter (not read by this launch)
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int2 it = wl.items[e];
         const long r = it.x, c = it.y;
@@ -353,9 +396,9 @@ void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, con
 
 // all right-hand-side panels in one launch
 void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                            const double* const* coefs, int metric, int i_pred, const double* pc, const double* pu,
+                            const double* const* coefs, int metric, int i_pred, double* pc, double* pu,
                             int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
-                            int n_panels, double* aux, CkWorklist wl) {
+                            int n_panels, double* aux, CkWorklist wl, const double* raw) {
     if (mpad <= 0 || n_panels <= 0) return;
     const int64_t np = L.npad;
     CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, pu, pu + mpad, pu + 2 * mpad};
@@ -363,7 +406,7 @@ void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const
     CkPanelMap pm{nullptr, nullptr, nullptr, n_panels, aux, (long)(mpad / 64)};
     dim3 grid((unsigned)(n_panels * (mpad / 64)));
     if (fast)
-        k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl);
+        k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl, raw, (long)mpad, pc, pu);
     else
         k_assemble<false, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl);
 }

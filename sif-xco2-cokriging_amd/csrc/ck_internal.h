@@ -29,10 +29,13 @@ struct CkLayout {
     long n0, n0p, nend, npad;
 };
 // entries the table kernels defer to the exact evaluator: (row, col) pairs + device counter
+// Two counters, used alternately (round 4): the pass that evaluates one assembly's list (k_assemble_fix) zeroes the counter
+// of the NEXT assembly, so that no assembly starts with a memset launch of its own.
 struct CkWorklist {
     int2* items;
     unsigned* count;
     unsigned cap;
+    unsigned* reset;   // the other counter (may be null)
 };
 // which panels one assembly launch covers: Sigma -- the owned panels (tile0[j] = index of the first
 // 64-row tile of the j-th owned panel, panel_of[j] = its block column, sigptr[K] = its storage);
@@ -52,10 +55,13 @@ void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, con
                               CkPanelMap pm, int total_tiles, CkWorklist wl);
 // right-hand-side rows, every block column in one launch: rows = prediction sites p in [0, m)
 // (row m = data values z, rows > m zero), cols = data sites.
+// raw (table path only; may be null): the prediction sites' coordinates as the caller gave them (m x 2, padded with zeros
+// to mpad).  The launch then transforms them itself -- every workgroup its own 64 rows, the workgroups of block column 0
+// also write pc / pu for the later users (exact pass, _verify_model) -- instead of waiting for a k_prep_sites launch.
 void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
-                            const double* const* coefs, int metric, int i_pred, const double* pc, const double* pu,
+                            const double* const* coefs, int metric, int i_pred, double* pc, double* pu,
                             int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
-                            int n_panels, double* aux, CkWorklist wl);
+                            int n_panels, double* aux, CkWorklist wl, const double* raw = nullptr);
 // evaluate the deferred entries of the preceding table-path launches (no-op when the list is empty)
 void ck_launch_assemble_fix(hipStream_t s, bool aux_rows, const CkMatern* blk, int metric, int i_pred,
                             const double* pc, int64_t mpad, const double* c, CkLayout L, CkWorklist wl,

@@ -230,7 +230,9 @@ CK_HD double ck_matern_rho_scaled(const CkMatern& m, double s) {
 // of rho itself grows (1e-12 at rho = 1e-14) while the absolute one keeps shrinking.
 // Coefficients are k-major with a fixed stride (coef[k * CK_TAB_STRIDE + interval]): lanes on
 // neighbouring intervals read neighbouring LDS banks and k becomes an immediate offset.
+#ifndef CK_TAB_DEG
 #define CK_TAB_DEG 7
+#endif
 #define CK_TAB_SHIFT 47            /* bits >> 47 = exponent and top 5 mantissa bits */
 #define CK_TAB_MAXINT 768          /* 24 octaves; 8 x 769 doubles = 48 KB of LDS */
 // k-stride in doubles.  NOT a multiple of 64: with a 512-byte-multiple stride hipcc fuses the
