@@ -200,7 +200,10 @@ __device__ __forceinline__ unsigned assemble_subtile_edge(const CkMatern& mb, in
                                                           int tbase, unsigned tn, const CkSiteRef& R,
                                                           const CkSiteRef& S, const double* __restrict__ z,
                                                           const CkLayout& L, long rt, long ct, long m, int nug,
-                                                          double* __restrict__ obase, int ty, int tx) {
+                                                          double* __restrict__ obase, int ty, int tx,
+                                                          const double* rowu = nullptr /* LDS: chord vectors of the strip's
+                                                          64 rows when the launch transforms them itself (R.u* is then being
+                                                          WRITTEN by the strips of block column 0 of the same launch) */) {
     unsigned slowmask = 0;
 #pragma unroll 1
     for (int ba = 0; ba < 8; ++ba) {
@@ -215,7 +218,9 @@ __device__ __forceinline__ unsigned assemble_subtile_edge(const CkMatern& mb, in
             const bool valid = rv && cv;
             double val = 0.0;
             if (FAST) {
-                const double dx = R.u0[r] - S.u0[c + e], dy = R.u1[r] - S.u1[c + e], dz = R.u2[r] - S.u2[c + e];
+                const double r0_ = rowu ? rowu[ty + 16 * a] : R.u0[r], r1_ = rowu ? rowu[64 + ty + 16 * a] : R.u1[r],
+                             r2_ = rowu ? rowu[128 + ty + 16 * a] : R.u2[r];
+                const double dx = r0_ - S.u0[c + e], dy = r1_ - S.u1[c + e], dz = r2_ - S.u2[c + e];
                 const double q = dx * dx + dy * dy + dz * dz;
                 int iv;
                 const double y = ck_table_y(q, &iv, tbase);
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
         // right-hand sides: the row tile that holds row m runs the interior code with its rows >= m replaced in front of the
         // store (ZROWS; thread row a is row m + (16 a - zrel))
         if (!FAST || (row_pad && !AUX) || range_has_padding(L, ct))
-            slowmask = assemble_subtile_edge<FAST, AUX>(mb, metric, lcoef, tbase, tn, R, S, z, L, rt, ct, m, nug, obase, ty, tx);
+            slowmask = assemble_subtile_edge<FAST, AUX>(mb, metric, lcoef, tbase, tn, R, S, z, L, rt, ct, m, nug, obase, ty, tx,
+                                                        (FAST && AUX && raw) ? srow : nullptr);
         else if (AUX && row_pad)
             slowmask = assemble_subtile_interior<true>(lcoef, tbase, tn, ru0, ru1, ru2, S, ct, obase, ty, tx, zrel, z);
         else

@@ -644,6 +644,37 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     assert info == 0 and np.array_equal(p3, ref[0]) and np.array_equal(e3, ref[1])
 
 
+@pytest.mark.parametrize("m", [100, 982])
+def test_right_hand_side_assembly_transforms_its_own_sites_and_reads_nothing_stale(native, m):
+    """K2 is ONE launch since round 4: every strip transforms its 64 prediction sites itself and the strips of block column 0
+    store them for the later users.  No strip may read those stored vectors inside the launch (the edge sub-tiles at the
+    process boundary and at the end of the matrix once did: a race that showed as results depending on the PREVIOUS call's
+    sites): a handle that has just predicted at other sites gives the bits of a fresh handle, repeatedly."""
+    from sif_xco2_cokriging_amd import synth
+    pb = synth.conus_problem(700, params=synth.SET_A, seed=5)       # n0 = 700: not a multiple of 64 -> edge sub-tiles
+    rng = np.random.default_rng(m)
+    pcs = [np.column_stack([rng.uniform(25, 49, m), rng.uniform(-124, -67, m)]) for _ in range(3)]
+    fresh = []
+    for pc in pcs:
+        h, _ = _assembled(native, pb["params"], pb["coords"], pb["values"], HAV)
+        assert h.factor() == 0
+        fresh.append(h.predict(0, pc))
+        h.close()
+    h, _ = _assembled(native, pb["params"], pb["coords"], pb["values"], HAV)
+    assert h.factor() == 0
+    fb = []
+    for rep in range(2):
+        for k in (0, 1, 2, 1):
+            h.table_fallbacks()
+            p, e = h.predict(0, pcs[k])
+            fb.append((k, h.table_fallbacks()))
+            assert np.array_equal(p, fresh[k][0]) and np.array_equal(e, fresh[k][1]), (rep, k)
+    assert len({c for k, c in fb if k == 1}) == 1           # the exact pass sees the same pairs every time
+    h.assemble_joint()                                       # ... and through the product call
+    info, p, e = h.factor_predict(0, pcs[2])
+    assert info == 0 and np.array_equal(p, fresh[2][0]) and np.array_equal(e, fresh[2][1])
+
+
 @pytest.mark.parametrize("entry", ["factor", "factor_predict", "factor_predict_two_sweeps"])
 def test_cooperative_panel_step_timeout_is_detected_and_the_factorisation_redone(native, entry):
     """k_panel_coop's safety net: option coop_inject_panel makes one workgroup of the diagonal block
