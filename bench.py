@@ -223,6 +223,9 @@ def main():
     for k in range(2):
         h.set_data(k, pb["coords"][k], pb["values"][k])
 
+    for kv in filter(None, os.environ.get("CK_BENCH_OPTIONS", "").split(",")):   # experiments: "name=value,..." -> ck_set_option
+        name, value = kv.split("=")
+        h.set_option(name.strip(), int(value))
     if world == 1:
         h.set_option("time_gemm", 1)
 

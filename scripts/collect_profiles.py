@@ -11,7 +11,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -29,9 +29,9 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
 st = glob.glob(f"{G}/prof_{tag}/trace/**/*kernel_stats.csv", recursive=True)
 if st:
     cp(st[0], f"{tag}_bench_n20k_kernel_stats.csv")
-so = glob.glob(f"{G}/prof_{tag}/trace_overlapped/**/*kernel_stats.csv", recursive=True)
+so = glob.glob(f"{G}/prof_{tag}/trace_sequential/**/*kernel_stats.csv", recursive=True)
 if so:
-    cp(so[0], f"{tag}_trace_overlapped_kernel_stats.csv")   # the default (overlapped) form of the same command
+    cp(so[0], f"{tag}_trace_sequential_kernel_stats.csv")   # --sweeps sequential: round 3's two kernels, each with the chip to itself
 cp(f"{G}/prof_{tag}_bench_line.json", f"{tag}_bench_n20k.json")
 cp(f"{G}/prof_{tag}_bench_config1.json", f"{tag}_bench_config1_n5k.json")
 cp(f"{G}/prof_{tag}_bench_n50k.json", f"{tag}_bench_n50k_1gpu.json")
@@ -48,46 +48,57 @@ for name, out in ((f"prof_vario_{tag}", f"{tag}_variogram_1M_kernel_stats.csv"),
     if f:
         cp(f[0], out)
 
-# ---- traffic of k_syrk_group_d -------------------------------------------------------------------
+# ---- traffic of k_tall_group_d -------------------------------------------------------------------
 fe, wr = f"{P}/{tag}_pmc_fetch_per_kernel_mean.csv", f"{P}/{tag}_pmc_write_per_kernel_mean.csv"
 if os.path.exists(fe) and os.path.exists(wr):
     f = pd.read_csv(fe).set_index("Kernel_Name")
     w = pd.read_csv(wr).set_index("Kernel_Name")
-    k = [x for x in f.index if x.startswith("k_syrk_group_d")][0]
+    k = [x for x in f.index if x.startswith("k_tall_group_d")][0]
     fetch_kb, write_kb = float(f.loc[k, "FETCH_SIZE"]), float(w.loc[k, "WRITE_SIZE"])
-    # algorithmic bytes of the 78 launches of one factorisation at N = 40 000 (Npad = 40 448, 79 panels, groups of 3):
-    # every C tile of a launch read once and written once, every operand panel row read once
-    NB, N = 512, 40000
+    # algorithmic bytes of the launches of one pass at N = 40 000, m = 8 833 (Npad = 40 448, 79 panels, groups of 3, mpad = 8 960;
+    # the schedule of ck_api.hip: tall_sweeps -- per group two in-group launches on one block column, then A / B1 / B2):
+    # every C tile of a launch (triangle + right-hand-side block) read once and written once, every operand row (panel rows of
+    # the target columns' row range + the right-hand-side rows) read once per source panel
+    NB, N, mpad, G = 512, 40000, 8960, 3
     nK = -(-N // NB)
     Np = nK * NB
+    ng = -(-nK // G)
+
+    def col_c(J):          # doubles of C in block column J: lower 128-tiles + right-hand-side block
+        return (Np - J * NB) * NB - NB * (NB - 128) // 2 + mpad * NB
+
+    def launch(K0, npan, J0, nJ):
+        c = sum(col_c(J) for J in range(J0, J0 + nJ))
+        rows = (Np - J0 * NB) + mpad          # operand rows read per source panel (A rows of the range + right-hand-side rows)
+        return 8 * (2 * c + npan * rows * NB)
     launches = []
-    for K0 in range(0, nK, 3):   # (79 panels: groups of three, no look-ahead -- the automatic schedule from 64 panels on)
-        Gc = min(3, nK - K0)
-        for g in range(1, Gc):
-            rows = Np - (K0 + g) * NB
-            c = rows * NB - NB * (NB - 128) // 2          # lower tiles of one block column (128-tiles on the diagonal kept whole)
-            launches.append(8 * (2 * c + g * rows * NB))
-        if K0 + Gc < nK:
-            c = sum((Np - J * NB) * NB - NB * (NB - 128) // 2 for J in range(K0 + Gc, nK))
-            rows = Np - (K0 + Gc) * NB
-            launches.append(8 * (2 * c + Gc * rows * NB))
+    for g in range(ng):
+        K0, Gc = g * G, min(G, nK - g * G)
+        for q in range(1, Gc):
+            launches.append(launch(K0, q, K0 + q, 1))
+        first = lambda x: x * G
+        count = lambda x: min(G, nK - x * G)
+        if g + 1 < ng:
+            launches.append(launch(K0, Gc, first(g + 1), count(g + 1)))
+        if g + 2 < ng:
+            launches.append(launch(K0, Gc, first(g + 2), count(g + 2)))
+        if g + 3 < ng:
+            launches.append(launch(K0, Gc, first(g + 3), nK - first(g + 3)))
     alg = sum(launches) / len(launches)
     out = {
-        "kernel": k, "launches_per_factorisation": len(launches),
+        "kernel": k, "launches_per_pass": len(launches),
         "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
         "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streams at 64 bytes "
-                            "(MI355X_MICROARCH.md, HBM section); the operand panels arrive through global_load_lds_dwordx4 "
+                            "(MI355X_MICROARCH.md, HBM section); the operand panels arrive through buffer_load_dwordx4 ... lds "
                             "(16 B per lane).  The C tile is read with 8-byte-per-lane loads, a width the guide calls uncalibrated: "
                             "doubling everything is the upper bound, the raw figure the lower.",
-        "fetch_bytes_corrected": 2 * fetch_kb * 1024, "write_bytes": write_kb * 1024,
-        "k_syrk_group_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-        "k_syrk_group_bytes_per_launch_uncorrected": fetch_kb * 1024 + write_kb * 1024,
+        "k_tall_group_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+        "k_tall_group_bytes_per_launch_uncorrected": fetch_kb * 1024 + write_kb * 1024,
         "algorithmic_bytes_per_launch": alg,
-        "traffic_over_algorithmic": (2 * fetch_kb * 1024 + write_kb * 1024) / alg,
-        "note": "mean per dispatch over the launches of k_syrk_group_d in the profiled bench run (warm-up, timed and cold pass; "
-                "N = 40 000, panel_group = 3); FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes "
-                "(scripts/profile_bench.sh), KB -> bytes.  Algorithmic bytes: each C tile of a launch read and written once, "
-                "each operand panel row read once, averaged over the same launches.",
+        "ratio_upper": (2 * fetch_kb * 1024 + write_kb * 1024) / alg,
+        "ratio_lower": (fetch_kb * 1024 + write_kb * 1024) / alg,
+        "note": "mean over the launches of one pass (the PMC passes run the default command: steps 1, warm-up 1 = two passes of "
+                "127 launches each); algorithmic = every C tile read and written once + every operand row read once per source panel",
     }
     json.dump(out, open(f"{P}/{tag}_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -4,7 +4,7 @@
 #   2. variogram (1 M soundings): kernel stats + SQ counters of the pair kernels
 #   3. local predictor (400 km): kernel stats + SQ counters of its matrix-core kernels
 # Outputs under gpurun_out/prof_<tag>*/ ; copy the summaries into profiles/ (scripts/collect_profiles.py).
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 scripts/profile_bench.sh $TAG > gpurun_out/prof_${TAG}_bench.txt 2>&1

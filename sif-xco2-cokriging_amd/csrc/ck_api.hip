@@ -2556,7 +2556,15 @@ extern "C" int ck_debug_stream_overlap(ck_handle* h, int mode, int64_t rows, int
     HIPCHK(hipMemcpyAsync(dP, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(dinfo, 0, 8, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    std::vector<hipEvent_t> ev(n_side + 2);
+    struct Events {   // destroyed on every return path (the HIPCHK early returns used to leak them)
+        std::vector<hipEvent_t> v;
+        ~Events() {
+            for (hipEvent_t e : v)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evs;
+    evs.v.assign((size_t)n_side + 2, nullptr);
+    std::vector<hipEvent_t>& ev = evs.v;
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     hipStream_t M = h->stream, S = h->side;
     HIPCHK(hipEventRecord(ev[0], M));
@@ -2583,7 +2591,6 @@ extern "C" int ck_debug_stream_overlap(ck_handle* h, int mode, int64_t rows, int
             out[1 + i] = ms;
         }
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     h->assembled = false;
     return 0;
 }

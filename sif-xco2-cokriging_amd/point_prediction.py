@@ -31,7 +31,7 @@ class Predictor:
     """Multivariate prediction framework (src/point_prediction.py:21-43)."""
 
     def __init__(self, mod, mf, covariates=None, dist_units: str = "km", fast_dist: bool = True, device: int = 0,
-                 devices=None):
+                 devices=None, reserve_scratch=None):
         """``devices=[0, 1, ...]``: the prediction points are sharded over one worker process per GPU (observations
         replicated, no exchange inside the computation) -- what ``partitions`` is to the reference's CPU pool
         (src/point_prediction.py:45-52, 69-81)."""
@@ -47,6 +47,13 @@ class Predictor:
         self.info = {}
         self._h = None
         self._key = None
+        # The reference builds its state -- the full Sigma blocks -- here, once (src/point_prediction.py:24-43).  Ours is the
+        # scratch slab of the large-neighbourhood paths: reserve_scratch = bytes, or "auto" for the library's budget (a quarter
+        # of the free device memory, at most 32 GiB), allocates it now so that no later call pays a hipMalloc of tens of GiB
+        # (up to seconds: include/cokrige.h, ck_local_reserve); None (default): grown by the first call that needs it.
+        self.reserve_scratch = reserve_scratch
+        if reserve_scratch is not None and (self.devices is None or len(self.devices) <= 1):
+            self._handle()
 
     def _handle(self):
         key = _JointPredictor._state_key(self)   # model parameters, metric, data: a change rebuilds the device state
@@ -60,6 +67,8 @@ class Predictor:
             h.set_metric(metric_of(self.dist_units, self.fast_dist))
             for k in range(self.n_procs):
                 h.set_data(k, self.mf.fields[k].coords_main, self.mf.fields[k].values_main)
+            if self.reserve_scratch is not None:
+                h.local_reserve(0 if self.reserve_scratch == "auto" else int(self.reserve_scratch))
             self._h = h
         return self._h
 
