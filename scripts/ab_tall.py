@@ -23,7 +23,13 @@ ref = None
 variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1}), ("tallT", {"tall_sweep": 1, "time_gemm": 1}),
             ("tallG1", {"tall_sweep": 1, "fused_group": 1}), ("tallG2", {"tall_sweep": 1, "fused_group": 2}),
             ("tallG4", {"tall_sweep": 1, "fused_group": 4}), ("tallG5", {"tall_sweep": 1, "fused_group": 5}),
-            ("tallG6", {"tall_sweep": 1, "fused_group": 6})]
+            ("tallG6", {"tall_sweep": 1, "fused_group": 6}),
+            ("tallF1", {"tall_sweep": 1, "group_first": 1}), ("tallG4F1", {"tall_sweep": 1, "fused_group": 4, "group_first": 1}),
+            ("tallG4F2", {"tall_sweep": 1, "fused_group": 4, "group_first": 2}),
+            ("tallF1T", {"tall_sweep": 1, "group_first": 1, "group_tail": 1, "group_tail_panels": 12}),
+            ("tallG4F1T", {"tall_sweep": 1, "fused_group": 4, "group_first": 1, "group_tail": 2, "group_tail_panels": 16}),
+            ("tallG4F1T1", {"tall_sweep": 1, "fused_group": 4, "group_first": 1, "group_tail": 1, "group_tail_panels": 12}),
+            ("tallG5F1", {"tall_sweep": 1, "fused_group": 5, "group_first": 1})]
 if len(sys.argv) > 3 and sys.argv[3] != "all":
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 N = 2 * n
@@ -35,6 +41,8 @@ for it in range(reps):
         h.set_option("fused_group", 0)
         h.set_option("tall_sweep", 1)
         h.set_option("time_gemm", 0)
+        for k_ in ("group_first", "group_tail", "group_tail_panels"):
+            h.set_option(k_, 0)
         for k_, v_ in opts.items():
             h.set_option(k_, v_)
         h.assemble_joint()

@@ -172,6 +172,7 @@ struct ck_handle {
     int fused_sweeps_opt = -1;        // ck_factor_predict: -1 automatic (overlapped up to 128 panels) | 0 sequential | 1 overlapped
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
+    int group_first = 0, group_tail = 0, group_tail_panels = 0;   // group_plan(): first group / last panels with other group sizes
     int tall_sweep = 1;               // ck_factor_predict: ONE sweep over the tall matrix [Sigma; c0^T; z^T] (tall_sweeps, round 4)
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
@@ -1064,6 +1065,29 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
 
 static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 3 : 1); }
 
+// Group boundaries of the single-process sweeps (every form -- ck_factor / ck_predict, the two overlapped sweeps, the tall
+// sweep -- takes them from here, so that all of them add a block column's updates up in the same order: same bits).
+// Groups of G panels; options "group_first" (panels of the FIRST group, 0 = G: a short first group shortens the one chain
+// nothing can hide, at the price of one pass over the matrix with a short K) and "group_tail" / "group_tail_panels" (group
+// size for the last so-many panels, where a group's updates are shorter than its chain).  starts[g] .. starts[g + 1] - 1.
+static std::vector<int> group_plan(const ck_handle* h, int G) {
+    std::vector<int> st;
+    G = std::max(1, G);
+    const int nK = h->nK;
+    int K = 0;
+    if (h->group_first > 0 && h->group_first < G && nK > h->group_first) {
+        st.push_back(0);
+        K = h->group_first;
+    }
+    const int tailG = h->group_tail > 0 ? std::min(h->group_tail, G) : G;
+    while (K < nK) {
+        st.push_back(K);
+        K += (nK - K <= h->group_tail_panels) ? tailG : G;
+    }
+    st.push_back(nK);
+    return st;
+}
+
 static bool factor_lookahead(const ck_handle* h) {
     if (h->lookahead >= 0) return h->lookahead != 0;
     return (h->panel_fused & 16) && h->panel_group == 0 && h->world == 1 && h->nK >= 12 && h->nK < 64;
@@ -1099,9 +1123,9 @@ static int factor_sweep(ck_handle* h) {
         // Groups of G panels: inside a group block column K first receives the updates of the group's
         // earlier panels in one pass (K dimension 512 g), then its panel step; the trailing matrix
         // beyond the group is updated once with K = 512 G -- a quarter of the C traffic of G = 1.
-        const int G = eff_group(h);
-        for (int K0 = 0; K0 < h->nK; K0 += G) {
-            const int Gc = std::min(G, h->nK - K0);
+        const std::vector<int> gs = group_plan(h, eff_group(h));
+        for (size_t gi = 0; gi + 1 < gs.size(); ++gi) {
+            const int K0 = gs[gi], Gc = gs[gi + 1] - gs[gi];
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
@@ -1143,9 +1167,9 @@ static int solve_sweep(ck_handle* h) {
         for (int K = 0; K < h->nK; ++K)
             if (ck_panel_apply(h, K, CK_APPLY_AUX)) return -1;
     } else {
-        const int G = eff_group(h);
-        for (int K0 = 0; K0 < h->nK; K0 += G) {
-            const int Gc = std::min(G, h->nK - K0);
+        const std::vector<int> gs = group_plan(h, eff_group(h));
+        for (size_t gi = 0; gi + 1 < gs.size(); ++gi) {
+            const int K0 = gs[gi], Gc = gs[gi + 1] - gs[gi];
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
@@ -1180,13 +1204,12 @@ static int fused_sweeps(ck_handle* h) {
     // option "fused_prio": 0 the factorisation on the high-priority stream | 1 the substitution | 2 neither
     hipStream_t F = h->fused_prio == 0 ? h->side : h->fused_prio == 1 ? h->stream : h->side_lo;
     hipStream_t M = h->fused_prio == 1 ? h->side : h->stream;
-    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    const std::vector<int> gs = group_plan(h, h->fused_group > 0 ? h->fused_group : eff_group(h));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (F != h->stream) HIPCHK(hipStreamWaitEvent(F, h->ev0, 0));
     if (M != h->stream) HIPCHK(hipStreamWaitEvent(M, h->ev0, 0));
-    int ge = 0;
-    for (int K0 = 0; K0 < h->nK; K0 += G, ++ge) {
-        const int Gc = std::min(G, h->nK - K0);
+    for (int ge = 0; ge + 1 < (int)gs.size(); ++ge) {
+        const int K0 = gs[ge], Gc = gs[ge + 1] - gs[ge];
         for (int g = 0; g < Gc; ++g) {
             if (g > 0) syrk_update(h, F, K0, g, K0 + g, 1, 1);
             panel_factor_on(h, K0 + g, F);
@@ -1225,10 +1248,10 @@ static int fused_sweeps_la(ck_handle* h) {
     if (ensure_events(h)) return -1;
     if (!h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
     hipStream_t C = h->side, T = h->side_lo, M = h->stream;
-    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
-    const int ng = (h->nK + G - 1) / G;
-    auto first = [&](int g) { return g * G; };
-    auto count = [&](int g) { return std::min(G, h->nK - g * G); };
+    const std::vector<int> gs = group_plan(h, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    const int ng = (int)gs.size() - 1;
+    auto first = [&](int g) { return gs[(size_t)g]; };
+    auto count = [&](int g) { return gs[(size_t)g + 1] - gs[(size_t)g]; };
     HIPCHK(hipEventRecord(h->ev0, M));
     HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
     HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
@@ -1281,10 +1304,10 @@ static int tall_sweeps(ck_handle* h) {
     if (ensure_events(h)) return -1;
     if (!h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
     hipStream_t C = h->side, T = h->side_lo, M = h->stream;
-    const int G = std::max(1, h->fused_group > 0 ? h->fused_group : eff_group(h));
-    const int ng = (h->nK + G - 1) / G;
-    auto first = [&](int g) { return g * G; };
-    auto count = [&](int g) { return std::min(G, h->nK - g * G); };
+    const std::vector<int> gs = group_plan(h, h->fused_group > 0 ? h->fused_group : eff_group(h));
+    const int ng = (int)gs.size() - 1;
+    auto first = [&](int g) { return gs[(size_t)g]; };
+    auto count = [&](int g) { return gs[(size_t)g + 1] - gs[(size_t)g]; };
     auto update = [&](hipStream_t st, int K0, int np, int J0, int nJ) {
         if (nJ <= 0) return;
         gemm_timed_begin(h, st);
@@ -2757,6 +2780,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "coop_inject_panel")) {   // tests: the bounded wait of k_panel_coop must trip and be recovered from
         if (value < -1) return fail("coop_inject_panel must be -1 (off) or a panel index");
         h->coop_inject_panel = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "group_first") || !strcmp(name, "group_tail") || !strcmp(name, "group_tail_panels")) {   // see group_plan()
+        if (value < 0 || value > 1024) return fail("group_first / group_tail / group_tail_panels must be in [0, 1024]");
+        (!strcmp(name, "group_first") ? h->group_first : !strcmp(name, "group_tail") ? h->group_tail : h->group_tail_panels) = (int)value;
         return 0;
     }
     if (!strcmp(name, "tall_sweep")) {   // see ck_handle::tall_sweep
