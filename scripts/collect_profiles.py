@@ -42,6 +42,9 @@ cp(f"{G}/prof_{tag}_local_pmc.txt", f"{tag}_local_400km_pmc.txt")
 cp(f"{G}/prof_{tag}_loocv.json", f"{tag}_loocv.json")
 cp(f"{G}/prof_{tag}_assembly.txt", f"{tag}_assembly_k1_k2.txt")
 cp(f"{G}/prof_{tag}_panel_step.txt", f"{tag}_panel_step.txt")
+cp(f"{G}/prof_{tag}_tall_ab.txt", f"{tag}_tall_sweep_ab.txt")
+cp(f"{G}/prof_{tag}_local_reserved.json", f"{tag}_local_predictor_reserved.json")
+cp(f"{G}/prof_{tag}_rccl_single_rank.txt", f"{tag}_rccl_single_rank.txt")
 cp(f"{G}/prof_{tag}_bench_2rank_gloo.json", f"{tag}_bench_2rank_gloo_one_gpu.json")
 for name, out in ((f"prof_vario_{tag}", f"{tag}_variogram_1M_kernel_stats.csv"), (f"prof_local_{tag}", f"{tag}_local_400km_kernel_stats.csv")):
     f = glob.glob(f"{G}/{name}/**/*kernel_stats.csv", recursive=True)
