@@ -319,7 +319,8 @@ int ck_debug_gemm_stamps(ck_handle* h, uint64_t* out_host, int64_t n_words, int6
  * in the tall sweep (option "tall_sweep", the default): [5]/[6] = sum of the durations / number of its update launches
  * (k_tall_group_d; launches of the two streams overlap each other, so the sum exceeds the span); [10] counts device work only
  * (counting pass + solve), [14] = host milliseconds the last ck_predict_local / ck_local_reserve spent growing the scratch slab
- * (hipMalloc; 0 when it did not grow); [15] reserved. */
+ * (hipMalloc; 0 when it did not grow); [15] after a tall sweep with "time_gemm": the union of the intervals of its update launches
+ * -- the time during which k_tall_group_d is running at all (its launches on the two streams overlap each other). */
 int ck_timings(ck_handle* h, double* out, int n);
 /* The assembly kernels evaluate the covariance through a per-block table of C = amp * rho over
  * the squared chord (built on the device from the exact K_nu evaluator and verified against it

@@ -795,16 +795,40 @@ static void gemm_timed_end(ck_handle* h, hipStream_t st = nullptr) {
 }
 
 // sum the event pairs recorded since the last reset into t_ms[slot], t_ms[slot + 1]
-static void gemm_timed_collect(ck_handle* h, int slot) {
+// ref != nullptr (the tall sweep: launches of two streams overlap each other): also the UNION of the launches' intervals --
+// the time during which the kernel is running at all -- into t_ms[15], from every launch's start / end relative to `ref`
+static void gemm_timed_collect(ck_handle* h, int slot, hipEvent_t ref = nullptr) {
     if (!h->time_gemm) return;
     double tot = 0;
+    std::vector<std::pair<float, float>> iv;
     for (size_t e = 0; e < h->gemm_ev_used; ++e) {
         float t = 0;
         (void)hipEventElapsedTime(&t, h->gemm_ev[e].a, h->gemm_ev[e].b);
         tot += t;
+        if (ref) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ref, h->gemm_ev[e].a);
+            (void)hipEventElapsedTime(&b, ref, h->gemm_ev[e].b);
+            iv.push_back({a, b});
+        }
     }
     h->t_ms[slot] = tot;
     h->t_ms[slot + 1] = (double)h->gemm_ev_used;
+    if (ref) {
+        std::sort(iv.begin(), iv.end());
+        double un = 0, cs = 0, ce = -1;
+        for (const auto& x : iv) {
+            if (x.first > ce) {
+                if (ce >= 0) un += ce - cs;
+                cs = x.first;
+                ce = x.second;
+            } else if (x.second > ce) {
+                ce = x.second;
+            }
+        }
+        if (ce >= 0) un += ce - cs;
+        h->t_ms[15] = un;
+    }
     h->gemm_ev_used = 0;
 }
 
@@ -1401,7 +1425,8 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     h->t_ms[3] = h->t_ms[13] - h->t_ms[1];   // what the substitution adds behind the factorisation
     h->t_ms[12] = 0.0;
     h->t_ms[5] = h->t_ms[6] = h->t_ms[7] = h->t_ms[8] = 0.0;
-    if (tall) gemm_timed_collect(h, 5);   // the tall sweep's update launches (sum of their durations; they overlap each other)
+    h->t_ms[15] = 0.0;
+    if (tall) gemm_timed_collect(h, 5, h->ev0);   // the tall sweep's update launches: sum of their durations and union of their intervals
     else h->gemm_ev_used = 0;
     if (ck_aux_finish(h, pred, pred_err)) return -1;
     h->aux_state = 2;

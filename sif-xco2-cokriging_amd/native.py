@@ -550,7 +550,7 @@ class Handle:
         _chk(lib().ck_timings(self._h, _p(out), 16))
         keys = ["assemble_sigma_ms", "factor_ms", "assemble_aux_ms", "solve_ms", "reduce_ms", "syrk_ms",
                 "syrk_launches", "aux_gemm_ms", "aux_gemm_launches", "vario_bin_ms", "local_ms", "verify_ms",
-                "panel_coop_redone", "fused_sweeps_ms", "local_alloc_ms", "reserved"]
+                "panel_coop_redone", "fused_sweeps_ms", "local_alloc_ms", "tall_union_ms"]
         return dict(zip(keys, out.tolist()))
 
     def dev_gemm_nt(self, C_ptr, ldc, A_ptr, lda, B_ptr, ldb, M, N, K, lower=False):
