@@ -184,6 +184,8 @@ struct ck_handle {
     int64_t local_slab_mb = 0;   // option "local_slab_mb": scratch budget of ck_predict_local (0 = automatic)
     int local_tile_min = 64;     // option "local_tile_min": neighbourhoods larger than this take the tiled path
     int local_group = 4;         // option "local_group": 64-column blocks per trailing update of the tiled path
+    int local_left = 1;          // option "local_left": the tiled path's groups are updated left-looking (one pass with K = g0 in front
+                                 // of each group) instead of right-looking (a K = 64 G update of everything behind each group)
     int panel_fused = 2 | 16;         // option "panel_fused", bit 0: factorisation, bit 1: right-hand-side rows --
                                       // left-looking 64-column sub-blocks inside a panel, fused launches (measured at
                                       // N = 40 000: solve sweep 228.2 -> 219.6 ms, factorisation 362.9 -> 365.0 ms);
@@ -2047,7 +2049,14 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
             for (int y = 0; y < nb; ++y) kqv[y] = sysv[tb.first + y].kq;
             int na = nb;
             const int G = h->local_group;
+            const bool left = h->local_left != 0 && 64 * G <= 256;
             for (int g0 = 0; g0 < kq_max; g0 += 64 * G) {
+                // left-looking (round 4): the group's columns first receive everything from their left in one pass (K = g0) --
+                // every tile of a system is read and written once instead of once per earlier group with K = 64 G
+                if (left && g0 > 0) {
+                    while (na > 0 && sysv[tb.first + na - 1].kq <= g0) --na;
+                    ck_launch_local_tiled_left(h->stream, bsys, d_slab, na, g0, 64 * G, kqv.data());
+                }
                 // the group's diagonal region block by block (diagonal block, then the few chunks of rows inside the region) ...
                 for (int b = 0; b < G && g0 + 64 * b < kq_max; ++b) {
                     while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * b) --na;   // finished systems drop off the end
@@ -2056,7 +2065,7 @@ extern "C" int ck_predict_local(ck_handle* h, int i, const double* pcoords, int6
                 // ... then every row below it through all of the group's blocks in one launch, then the trailing update
                 while (na > 0 && sysv[tb.first + na - 1].kq <= g0 + 64 * G) --na;
                 ck_launch_local_tiled_rows_all(h->stream, bsys, d_slab, na, g0, G, kqv.data());
-                ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kqv.data());
+                if (!left) ck_launch_local_tiled_trailing(h->stream, bsys, d_slab, na, g0, 64 * G, kqv.data());
             }
             ck_launch_local_reduce_t(h->stream, bsys, nb, d_slab, d_linfo + tb.first, c0var, d_out, d_out + mp);
             HIPCHK(hipGetLastError());
@@ -2810,6 +2819,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "group_first") || !strcmp(name, "group_tail") || !strcmp(name, "group_tail_panels")) {   // see group_plan()
         if (value < 0 || value > 1024) return fail("group_first / group_tail / group_tail_panels must be in [0, 1024]");
         (!strcmp(name, "group_first") ? h->group_first : !strcmp(name, "group_tail") ? h->group_tail : h->group_tail_panels) = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "local_left")) {   // see ck_handle::local_left
+        if (value < 0 || value > 1) return fail("local_left must be 0 or 1");
+        h->local_left = (int)value;
         return 0;
     }
     if (!strcmp(name, "tall_sweep")) {   // see ck_handle::tall_sweep

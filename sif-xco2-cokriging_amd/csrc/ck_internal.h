@@ -235,5 +235,9 @@ void ck_launch_local_tiled_rows_all(hipStream_t s, const CkLocalSys* sys, double
                                     int group_blocks, const int* kq_host);
 void ck_launch_local_tiled_trailing(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int K,
                                     const int* kq_host);
+// left-looking form (round 4, option "local_left" = 1, the default): the columns [g0, g0 + W) of every system, rows g0 .., receive
+// all updates from the columns to their left in ONE pass (K = g0) before the group is factored; W <= 256
+void ck_launch_local_tiled_left(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int W,
+                                const int* kq_host);
 void ck_launch_local_reduce_t(hipStream_t s, const CkLocalSys* sys, int n_sys, const double* slab,
                               const long long* info, double c0var, double* pred, double* err);

@@ -1663,6 +1663,56 @@ __global__ __launch_bounds__(512, 4) void k_lt_update(const CkLocalSys* __restri
     gemm_tile_e<true>(S + (long)o * q.ld + o, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, K, lds, q.kq - o, q.kq - o, true);
 }
 
+// LEFT-LOOKING update of a column group (round 4): before the group [g0, g0 + W) is factored, its columns -- rows g0 .. kq - 1,
+// lower tiles only -- receive the updates of EVERYTHING to their left in one pass,
+//     C[g0 .., g0 .. g0 + W) -= S[g0 .., 0 .. g0) * S[g0 .. g0 + W, 0 .. g0)^T        (K = g0).
+// The right-looking form (k_lt_update after every group) read and wrote every trailing tile once per earlier group with K = 64 G
+// = 256 -- a tile's C traffic was most of its life (0.74 of the peak); here every tile of the matrix is read and written ONCE, with
+// a K loop as long as the matrix to its left.  The sequence of accumulations per element is the same (k ascending, the same
+// groups of four per MFMA; the sign flips between the passes of the right-looking form were exact), so the factor keeps its bits.
+__global__ __launch_bounds__(512, 4) void k_lt_left(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0, int W,
+                                                     const CkRunMap map) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
+    int y, t;
+    if (!ck_runmap_get(map, (int)blockIdx.x, y, t)) return;
+    const CkLocalSys q = sys[y];
+    const int rows = q.kq - g0;                       // rows (and columns) of the trailing matrix that starts at g0
+    if (rows <= 0) return;
+    const int w = rows < W ? rows : W;                // the group's columns inside this system
+    const int Tr = (rows + 127) / 128, Tc = (w + 127) / 128;   // Tc = 1 or 2 (W <= 256): tile (0, 1) lies above the diagonal
+    const int ntile = Tr * Tc - (Tc == 2 ? 1 : 0);
+    if (t >= ntile) return;
+    int tm, tn;
+    if (Tc == 1) {
+        tm = t;
+        tn = 0;
+    } else if (t == 0) {
+        tm = 0;
+        tn = 0;
+    } else {
+        tm = (t + 1) >> 1;
+        tn = (t + 1) & 1;
+    }
+    double* S = slab + q.off;
+    const double* A = S + (long)g0 * q.ld;            // rows g0 .., columns 0 .. g0 - 1: both operands
+    gemm_tile_e<true>(S + (long)g0 * q.ld + g0, q.ld, A, q.ld, A, q.ld, (long)tm * 128, (long)tn * 128, g0, lds, rows, w, true);
+}
+
+// the group [g0, g0 + W) of the first n_active systems (those with kq > g0): W <= 256
+void ck_launch_local_tiled_left(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int W,
+                                const int* kq_host) {
+    if (n_active <= 0 || g0 <= 0) return;
+    const CkRunMap map = ck_runmap_make(n_active, [&](int y) {
+        const int rows = kq_host[y] - g0;
+        if (rows <= 0) return 0;
+        const int w = rows < W ? rows : W;
+        const int Tr = (rows + 127) / 128, Tc = (w + 127) / 128;
+        return Tr * Tc - (Tc == 2 ? 1 : 0);
+    });
+    if (map.nruns == 0) return;
+    k_lt_left<<<dim3((unsigned)map.off[map.nruns]), dim3(512), 0, s>>>(sys, slab, g0, W, map);
+}
+
 // block i of the group at g0 for the first n_active systems (those with kq > g0 + 64 i)
 void ck_launch_local_tiled_block(hipStream_t s, const CkLocalSys* sys, double* slab, int n_active, int g0, int i,
                                  const int* kq_host, long long* info, int group_blocks) {
