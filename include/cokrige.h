@@ -365,7 +365,12 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by
  * the tiled path of ck_predict_local (batched 64-column steps on the matrix cores) instead of one workgroup per
  * point (in LDS up to 64 sites, on a global slab above);
- * "local_group" (1..8, default 4) = 64-column blocks per trailing update of that path;
+ * "local_group" (1..8, default 4) = 64-column blocks per group of that path; "local_left" (0/1, default 1): a group's columns receive
+ * everything from their left in one pass (K = the group's first column) before the group is factored, instead of a K = 64 x
+ * local_group update of everything behind every group (same bits: the accumulation order per element is the same);
+ * "group_first" / "group_tail" / "group_tail_panels" (default 0 = off): the single-process sweeps' group boundaries -- a first group
+ * of so many panels, groups of group_tail panels for the last group_tail_panels panels (every form of the sweep takes its
+ * boundaries from one plan, so all of them keep one summation order; measured: no gain);
  * "site_order" (0/1, default 1; changing it after the first assemble lays the sites out again): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
  * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,
