@@ -30,7 +30,7 @@ for trial in range(ntrial):
     pc = pb["pcoords"][rng.permutation(len(pb["pcoords"]))[:m]]
     h = native.Handle(0)
     opts = {"site_order": int(rng.integers(0, 2)), "panel_group": int(rng.integers(0, 5)),
-            "panel_fused": int(rng.integers(0, 4)), "exact_cov": int(rng.random() < 0.2)}
+            "panel_fused": int(rng.choice([0, 1, 2, 3, 16, 18, 18, 18, 18])), "exact_cov": int(rng.random() < 0.2)}
     for k, v in opts.items():
         h.set_option(k, v)
     if uni:
@@ -47,7 +47,11 @@ for trial in range(ntrial):
     i = 0 if uni else int(rng.integers(0, 2))
     fused = rng.random() < 0.6    # ck_factor_predict: the two sweeps overlapped, random stream assignment / grouping / look-ahead
     if fused:
-        fo = {"fused_prio": int(rng.integers(0, 3)), "fused_group": int(rng.integers(0, 5)), "fused_la": int(rng.integers(-1, 2))}
+        # (round 4: with the cooperative panel step -- panel_fused bit 4 -- the call is ONE sweep over the tall matrix unless tall_sweep = 0;
+        # group plans with a short first group / small groups at the tail)
+        fo = {"fused_prio": int(rng.integers(0, 3)), "fused_group": int(rng.integers(0, 5)), "fused_la": int(rng.integers(-1, 2)),
+              "tall_sweep": int(rng.random() < 0.75), "group_first": int(rng.integers(0, 3)), "group_tail": int(rng.integers(0, 3)),
+              "group_tail_panels": int(rng.integers(0, 6))}
         for k, v in fo.items():
             h.set_option(k, v)
         opts.update(fo)
