@@ -520,7 +520,7 @@ def main():
                 flops = trailing_update_flops(N)
                 syrk_s = np.mean([t["syrk_ms"] for t in tim]) / 1e3
                 out["roofline"] = {
-                    "kernel": "k_syrk_group_d (Cholesky trailing update over 3-panel groups, v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging)",
+                    "kernel": "k_syrk_group_d (Cholesky trailing update over panel groups, v_mfma_f64_16x16x4_f64, 128x128 tiles, 8 waves, LDS-DMA staging)",
                     "bound": "mfma", "achieved": flops / syrk_s / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / syrk_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
                     "traffic": None, "traffic_source": None,

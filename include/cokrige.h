@@ -342,7 +342,7 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * short against the panel step and the one-launch cooperative panel step, submitted in front of the update, really runs
  * beside it: N = 10 000: 12.8 -> 11.4 ms), grouped updates without it from 64 panels on; 1 also switches the solve sweep's
  * variant on;
- * "panel_group" (1..16; default 0 = automatic: 3 for 40 or more panels, else 1) = panels per trailing update of
+ * "panel_group" (1..16; default 0 = automatic: 4 for 40 or more panels (3 in rounds 1-3), else 1) = panels per trailing update of
  * ck_factor / ck_predict;
  * "panel_fused" (0..31, default 18 = 2 | 16; bit 0: factorisation, bit 1: right-hand-side rows): inside a 512-column panel the
  * 64-column sub-blocks are processed left-looking with the update and the row solve fused into one launch; bit 2: the
@@ -368,9 +368,11 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * "local_group" (1..8, default 4) = 64-column blocks per group of that path; "local_left" (0/1, default 1): a group's columns receive
  * everything from their left in one pass (K = the group's first column) before the group is factored, instead of a K = 64 x
  * local_group update of everything behind every group (same bits: the accumulation order per element is the same);
- * "group_first" / "group_tail" / "group_tail_panels" (default 0 = off): the single-process sweeps' group boundaries -- a first group
- * of so many panels, groups of group_tail panels for the last group_tail_panels panels (every form of the sweep takes its
- * boundaries from one plan, so all of them keep one summation order; measured: no gain);
+ * "group_first" (default -1 = automatic: half a group from 40 panels on; 0 = a whole group) / "group_tail" / "group_tail_panels"
+ * (default 0 = off): the single-process sweeps' group boundaries -- a first group of so many panels, groups of group_tail panels for
+ * the last group_tail_panels panels (every form of the sweep takes its boundaries from one plan, so all of them keep one summation
+ * order; measured, DESIGN.md section 5: groups of four with a first group of two are 0.6 % ahead of groups of three, the tail
+ * variants change nothing);
  * "site_order" (0/1, default 1; changing it after the first assemble lays the sites out again): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and
  * columns of an assembly tile are neighbours in space (fewer LDS bank conflicts in the table lookups,

@@ -20,7 +20,7 @@ for k in range(2):
     h.set_data(k, pb["coords"][k], pb["values"][k])
 pc = pb["pcoords"]
 ref = None
-variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1}), ("tallT", {"tall_sweep": 1, "time_gemm": 1}),
+variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1}), ("tallG3", {"tall_sweep": 1, "fused_group": 3, "panel_group": 3, "group_first": 0}), ("tallT", {"tall_sweep": 1, "time_gemm": 1}),
             ("tallG1", {"tall_sweep": 1, "fused_group": 1}), ("tallG2", {"tall_sweep": 1, "fused_group": 2}),
             ("tallG4", {"tall_sweep": 1, "fused_group": 4}), ("tallG5", {"tall_sweep": 1, "fused_group": 5}),
             ("tallG6", {"tall_sweep": 1, "fused_group": 6}),
@@ -29,7 +29,11 @@ variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1
             ("tallF1T", {"tall_sweep": 1, "group_first": 1, "group_tail": 1, "group_tail_panels": 12}),
             ("tallG4F1T", {"tall_sweep": 1, "fused_group": 4, "group_first": 1, "group_tail": 2, "group_tail_panels": 16}),
             ("tallG4F1T1", {"tall_sweep": 1, "fused_group": 4, "group_first": 1, "group_tail": 1, "group_tail_panels": 12}),
-            ("tallG5F1", {"tall_sweep": 1, "fused_group": 5, "group_first": 1})]
+            ("tallG5F1", {"tall_sweep": 1, "fused_group": 5, "group_first": 1}),
+            ("tallG4F3", {"tall_sweep": 1, "fused_group": 4, "group_first": 3}), ("tallG5F2", {"tall_sweep": 1, "fused_group": 5, "group_first": 2}),
+            ("tallG5F3", {"tall_sweep": 1, "fused_group": 5, "group_first": 3}), ("tallG6F2", {"tall_sweep": 1, "fused_group": 6, "group_first": 2}),
+            ("tallG6F3", {"tall_sweep": 1, "fused_group": 6, "group_first": 3}), ("tallG3F2", {"tall_sweep": 1, "fused_group": 3, "group_first": 2}),
+            ("tallG4F2T", {"tall_sweep": 1, "fused_group": 4, "group_first": 2, "group_tail": 2, "group_tail_panels": 12})]
 if len(sys.argv) > 3 and sys.argv[3] != "all":
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 N = 2 * n
@@ -41,7 +45,8 @@ for it in range(reps):
         h.set_option("fused_group", 0)
         h.set_option("tall_sweep", 1)
         h.set_option("time_gemm", 0)
-        for k_ in ("group_first", "group_tail", "group_tail_panels"):
+        h.set_option("group_first", -1)
+        for k_ in ("group_tail", "group_tail_panels"):
             h.set_option(k_, 0)
         for k_, v_ in opts.items():
             h.set_option(k_, v_)

@@ -58,14 +58,15 @@ if os.path.exists(fe) and os.path.exists(wr):
     w = pd.read_csv(wr).set_index("Kernel_Name")
     k = [x for x in f.index if x.startswith("k_tall_group_d")][0]
     fetch_kb, write_kb = float(f.loc[k, "FETCH_SIZE"]), float(w.loc[k, "WRITE_SIZE"])
-    # algorithmic bytes of the launches of one pass at N = 40 000, m = 8 833 (Npad = 40 448, 79 panels, groups of 3, mpad = 8 960;
+    # algorithmic bytes of the launches of one pass at N = 40 000, m = 8 833 (Npad = 40 448, 79 panels, a first group of 2 panels then groups of 4, mpad = 8 960;
     # the schedule of ck_api.hip: tall_sweeps -- per group two in-group launches on one block column, then A / B1 / B2):
     # every C tile of a launch (triangle + right-hand-side block) read once and written once, every operand row (panel rows of
     # the target columns' row range + the right-hand-side rows) read once per source panel
-    NB, N, mpad, G = 512, 40000, 8960, 3
+    NB, N, mpad, G = 512, 40000, 8960, 4
     nK = -(-N // NB)
     Np = nK * NB
-    ng = -(-nK // G)
+    starts = [0] + list(range(G // 2, nK, G)) + [nK]      # group_plan(): a first group of G / 2 panels, then groups of G
+    ng = len(starts) - 1
 
     def col_c(J):          # doubles of C in block column J: lower 128-tiles + right-hand-side block
         return (Np - J * NB) * NB - NB * (NB - 128) // 2 + mpad * NB
@@ -76,11 +77,11 @@ if os.path.exists(fe) and os.path.exists(wr):
         return 8 * (2 * c + npan * rows * NB)
     launches = []
     for g in range(ng):
-        K0, Gc = g * G, min(G, nK - g * G)
+        K0, Gc = starts[g], starts[g + 1] - starts[g]
         for q in range(1, Gc):
             launches.append(launch(K0, q, K0 + q, 1))
-        first = lambda x: x * G
-        count = lambda x: min(G, nK - x * G)
+        first = lambda x: starts[x]
+        count = lambda x: starts[x + 1] - starts[x]
         if g + 1 < ng:
             launches.append(launch(K0, Gc, first(g + 1), count(g + 1)))
         if g + 2 < ng:

@@ -172,7 +172,7 @@ struct ck_handle {
     int fused_sweeps_opt = -1;        // ck_factor_predict: -1 automatic (overlapped up to 128 panels) | 0 sequential | 1 overlapped
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
-    int group_first = 0, group_tail = 0, group_tail_panels = 0;   // group_plan(): first group / last panels with other group sizes
+    int group_first = -1, group_tail = 0, group_tail_panels = 0;   // group_plan(): first group (-1 automatic) / last panels with other group sizes
     int tall_sweep = 1;               // ck_factor_predict: ONE sweep over the tall matrix [Sigma; c0^T; z^T] (tall_sweeps, round 4)
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
@@ -1089,7 +1089,9 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
     return 0;
 }
 
-static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 3 : 1); }
+// automatic: 4 from 40 panels on (round 4; 3 in rounds 1-3: interleaved A/B at N = 40 000, G = 3 / 4 / 5 / 6 with their best first
+// groups: 491.0 / 488.2 / 489.5 / 489.2 ms), 1 below
+static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 4 : 1); }
 
 // Group boundaries of the single-process sweeps (every form -- ck_factor / ck_predict, the two overlapped sweeps, the tall
 // sweep -- takes them from here, so that all of them add a block column's updates up in the same order: same bits).
@@ -1101,9 +1103,12 @@ static std::vector<int> group_plan(const ck_handle* h, int G) {
     G = std::max(1, G);
     const int nK = h->nK;
     int K = 0;
-    if (h->group_first > 0 && h->group_first < G && nK > h->group_first) {
+    // automatic (-1): from 40 panels on the first group has G / 2 panels -- the one chain nothing can hide under is half as long,
+    // for one pass over the matrix with K = 512 G / 2 (G = 4: 489.3 -> 488.2 ms)
+    const int gf = h->group_first >= 0 ? h->group_first : (nK >= 40 ? G / 2 : 0);
+    if (gf > 0 && gf < G && nK > gf) {
         st.push_back(0);
-        K = h->group_first;
+        K = gf;
     }
     const int tailG = h->group_tail > 0 ? std::min(h->group_tail, G) : G;
     while (K < nK) {
@@ -2817,7 +2822,7 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
         return 0;
     }
     if (!strcmp(name, "group_first") || !strcmp(name, "group_tail") || !strcmp(name, "group_tail_panels")) {   // see group_plan()
-        if (value < 0 || value > 1024) return fail("group_first / group_tail / group_tail_panels must be in [0, 1024]");
+        if (value < (strcmp(name, "group_first") ? 0 : -1) || value > 1024) return fail("group_first (-1 = automatic) / group_tail / group_tail_panels must be in [0, 1024]");
         (!strcmp(name, "group_first") ? h->group_first : !strcmp(name, "group_tail") ? h->group_tail : h->group_tail_panels) = (int)value;
         return 0;
     }

@@ -7,7 +7,7 @@ thousand sites) nor the library itself: the reference's lines src/joint_predicti
   * the vendor's dense solver (torch.linalg.cholesky / cholesky_solve = rocSOLVER) as a TEST cross-check (SURVEY.md
     appendix B allows exactly that use), NOT the hand-written blocked factorisation.
 
-So the product's whole chain at N = 40 000 -- Hilbert layout, tables + exact pass, grouped (G = 3) MFMA Cholesky, fused
+So the product's whole chain at N = 40 000 -- Hilbert layout, tables + exact pass, grouped (G = 4) MFMA Cholesky, fused
 forward sweep, reductions -- is compared with an independent chain on the same inputs.  At N = 100 000 the dense matrix
 (80 GB) is not formed: sampled rows of the factor are checked through (L L^T)[r, c] = Sigma[r, c].
 """
@@ -62,9 +62,9 @@ def test_n40000_prediction_vs_exact_entries_and_vendor_solver():
         p, e = h.predict(i, pc)                          # the FULL grid, as the bench does; compared at the sampled points
         got[i] = (p[cols], e[cols])
         full[i] = (p, e)
-    assert h.num_panels()[0] == 79                       # grouped (G = 3) sweeps are the default from 40 panels on
+    assert h.num_panels()[0] == 79                       # grouped sweeps (G = 4, a first group of two) are the default from 40 panels on
     # THE PRODUCT SCHEDULE at this size: what Predictor.__call__, smoke() and the bench's timed step
-    # run -- ck_factor_predict with its DEFAULT options: 79 panels, groups of three, one sweep over the tall matrix
+    # run -- ck_factor_predict with its DEFAULT options: 79 panels, groups of four behind a first group of two, one sweep over the tall matrix
     # [Sigma; c0^T; z^T] with the look-ahead on two streams -- on a fresh handle: the same bits as ck_factor + ck_predict
     # above on all 8 833 points, hence the same distance to the independent chain below.
     hp = _handle(pb)
@@ -81,7 +81,7 @@ def test_n40000_prediction_vs_exact_entries_and_vendor_solver():
     info, pq, pqe = hp.factor_predict(0, pc)
     assert info == 0 and hp.timings()["fused_sweeps_ms"] > 0
     assert np.array_equal(pq, full[0][0]) and np.array_equal(pqe, full[0][1])
-    print(f"N = 40 000: ck_factor_predict (defaults: tall sweep, G = 3, look-ahead; {tp['fused_sweeps_ms']:.1f} ms) == "
+    print(f"N = 40 000: ck_factor_predict (defaults: tall sweep, G = 4 behind a first group of 2, look-ahead; {tp['fused_sweeps_ms']:.1f} ms) == "
           "ck_factor + ck_predict bit for bit on 8 833 points, both processes")
     hp.close()
     S = _exact_sigma_gpu(h, coords)

@@ -148,7 +148,7 @@ def test_config3_properties_n20000():
 
 def test_defaults_across_the_schedule_boundaries_agree_with_the_plain_schedule():
     """The factorisation picks its schedule by size -- per-panel updates below 12 panels, the panel step on a second
-    stream under the update from 12 to 63, groups of three panels from 64 on (40 without the cooperative panel step) --:
+    stream under the update from 12 to 63, groups of four panels from 64 on (40 without the cooperative panel step) --:
     at 14 panels (N = 7 000: the automatic look-ahead) the default agrees with the strictly sequential, one-launch-per-
     dependency schedule to rounding, for both processes, and reports a not-positive-definite Sigma at the same index."""
     from sif_xco2_cokriging_amd import native, synth
