@@ -370,8 +370,8 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * local_group update of everything behind every group (same bits: the accumulation order per element is the same);
  * "group_first" (default -1 = automatic: half a group from 40 panels on; 0 = a whole group) / "group_tail" / "group_tail_panels"
  * (default 0 = off): the single-process sweeps' group boundaries -- a first group of so many panels, groups of group_tail panels for
- * the last group_tail_panels panels (every form of the sweep takes its boundaries from one plan, so all of them keep one summation
- * order; measured, DESIGN.md section 5: groups of four with a first group of two are 0.6 % ahead of groups of three, the tail
+ * the last group_tail_panels panels (the grouping does not change a bit of the results: an element's updates are accumulated k
+ * ascending whatever the split; measured, DESIGN.md section 5: groups of four with a first group of two are 0.6 % ahead of groups of three, the tail
  * variants change nothing);
  * "site_order" (0/1, default 1; changing it after the first assemble lays the sites out again): 1 lays the sites of each process -- and
  * sets of >= 256 prediction points -- out along a Hilbert curve inside the library, so that the rows and

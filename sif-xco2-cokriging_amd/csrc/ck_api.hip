@@ -1094,7 +1094,8 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
 static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 4 : 1); }
 
 // Group boundaries of the single-process sweeps (every form -- ck_factor / ck_predict, the two overlapped sweeps, the tall
-// sweep -- takes them from here, so that all of them add a block column's updates up in the same order: same bits).
+// sweep -- takes them from here).  The grouping does not touch the results: an element's updates are accumulated k ascending inside
+// a launch and the tile is stored and re-read exactly between launches, so any split performs the same MFMAs per element.
 // Groups of G panels; options "group_first" (panels of the FIRST group, 0 = G: a short first group shortens the one chain
 // nothing can hide, at the price of one pass over the matrix with a short K) and "group_tail" / "group_tail_panels" (group
 // size for the last so-many panels, where a group's updates are shorter than its chain).  starts[g] .. starts[g + 1] - 1.

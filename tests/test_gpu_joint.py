@@ -620,7 +620,7 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     pc = np.column_stack([rng.uniform(25, 49, m), rng.uniform(-124, -67, m)])
     h, p = _assembled(native, params, coords, values, HAV)
     if group:
-        h.set_option("panel_group", group)      # the sequence with the same grouping = the same summation order
+        h.set_option("panel_group", group)      # (any grouping gives the same bits; the sequence takes the same one anyway)
     assert h.factor() == 0
     ref = h.predict(1, pc)
     h2, _ = _assembled(native, params, coords, values, HAV)
@@ -761,8 +761,9 @@ def test_factor_predict_many_panels_every_schedule(native, prio, group, la):
     h2.set_option("fused_la", la)     # three streams: chain + next group's update / bulk / substitution
     info, pred, err = h2.factor_predict(1, pc)
     assert info == 0
-    tol = 0.0 if group == 0 else 1e-11      # another grouping: another summation order
-    assert rel(pred, ref[0]) <= tol and rel(err, ref[1]) <= tol
+    # ANY grouping gives the same bits: an element's updates are accumulated k ascending inside a launch and the tile is stored and
+    # re-read exactly between launches
+    assert np.array_equal(pred, ref[0]) and np.array_equal(err, ref[1])
     assert h2.timings()["fused_sweeps_ms"] > 0
 
 
