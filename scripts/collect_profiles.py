@@ -101,8 +101,8 @@ if os.path.exists(fe) and os.path.exists(wr):
         "algorithmic_bytes_per_launch": alg,
         "ratio_upper": (2 * fetch_kb * 1024 + write_kb * 1024) / alg,
         "ratio_lower": (fetch_kb * 1024 + write_kb * 1024) / alg,
-        "note": "mean over the 381 launches of a PMC pass (the default command with steps 1, warm-up 1 and its cold PCIe-inclusive pass "
-                "= three passes of 127 launches each, dispatches serialised by the profiler); algorithmic = every C tile read and written once + every operand row read once per source panel",
+        "note": f"mean over the {3 * len(launches)} launches of a PMC pass (the default command with steps 1, warm-up 1 and its cold PCIe-inclusive pass "
+                f"= three passes of {len(launches)} launches each, dispatches serialised by the profiler); algorithmic = every C tile read and written once + every operand row read once per source panel",
     }
     json.dump(out, open(f"{P}/{tag}_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
