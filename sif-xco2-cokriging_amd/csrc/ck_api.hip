@@ -112,6 +112,7 @@ struct ck_handle {
     double** d_sigptr = nullptr;
     double** d_panelptr = nullptr;   // where panel K can be read on this rank: own storage or receive buffer K & 1
     int *d_tile0 = nullptr, *d_panel_of = nullptr;   // assembly launch map of the owned panels
+    int* d_strip_order = nullptr;                    // the same strips sorted by Matern block (work-queue form of the assembly)
     int n_owned = 0, total_tiles = 0;
     // receive slots for remote panels (world > 1): panel K lands in slot K % recv_slots.  Two slots carry the per-panel
     // look-ahead schedule; 2 G slots the grouped one (the G panels of the group being applied + the G being received)
@@ -173,6 +174,8 @@ struct ck_handle {
     int fused_prio = 0;               // ck_factor_predict: which sweep runs on the high-priority stream (fused_sweeps)
     int fused_group = 0;              // ck_factor_predict: panels per group, 0 = as ck_factor
     int group_first = -1, group_tail = 0, group_tail_panels = 0;   // group_plan(): first group (-1 automatic) / last panels with other group sizes
+    int assemble_queue = -1;          // option "assemble_queue": resident workgroups of the table-path assembly kernels on a work queue
+                                      // (-1 automatic: 768 from 8 strips per workgroup on; 0 = one strip per workgroup)
     int tall_sweep = 1;               // ck_factor_predict: ONE sweep over the tall matrix [Sigma; c0^T; z^T] (tall_sweeps, round 4)
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
@@ -414,10 +417,10 @@ static int build_tables(ck_handle* h, double qbox_euclid) {
     if (!h->wl.items) {
         h->wl.cap = 1u << 22;   // 4 M deferred entries (32 MB); beyond that the assembly re-runs exactly
         HIPCHK(hipMalloc((void**)&h->wl.items, (size_t)h->wl.cap * sizeof(int2)));
-        HIPCHK(hipMalloc((void**)&h->wl_counts, 2 * sizeof(unsigned)));   // used alternately: see CkWorklist
-        HIPCHK(hipMemset(h->wl_counts, 0, 2 * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&h->wl_counts, 4 * sizeof(unsigned)));   // two pairs (count, work queue), used alternately: see CkWorklist
+        HIPCHK(hipMemset(h->wl_counts, 0, 4 * sizeof(unsigned)));
         h->wl.count = h->wl_counts;
-        h->wl.reset = h->wl_counts + 1;
+        h->wl.reset = h->wl_counts + 2;
     }
     const int ND = CK_TAB_DEG + 1;
     if (!h->d_tabs) {
@@ -574,6 +577,24 @@ static int ensure_panels(ck_handle* h) {
         HIPCHK(hipMalloc((void**)&h->d_panel_of, (panel_of.size() + 1) * sizeof(int)));
         HIPCHK(hipMemcpy(h->d_tile0, tile0.data(), tile0.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_panel_of, panel_of.data(), panel_of.size() * sizeof(int), hipMemcpyHostToDevice));
+        {
+            // work-queue form of the assembly: the 64-row strips of all owned panels sorted by Matern block (block 22 first, then
+            // 12, then 11; inside a block back to front as before), so that a resident workgroup reloads its table twice per launch
+            std::vector<int> order;
+            order.reserve((size_t)acc);
+            for (int cls = 2; cls >= 0; --cls)
+                for (int j = (int)panel_of.size() - 1; j >= 0; --j) {
+                    const int64_t K = panel_of[(size_t)j];
+                    const int pc = K * CK_NB >= h->n0p ? 1 : 0;
+                    for (int tile = tile0[(size_t)j + 1] - tile0[(size_t)j] - 1; tile >= 0; --tile) {
+                        const int64_t rt = K * CK_NB + (int64_t)tile * 64;
+                        if ((rt >= h->n0p ? 1 : 0) + pc == cls) order.push_back(tile0[(size_t)j] + tile);
+                    }
+                }
+            HIPCHK(hipMalloc((void**)&h->d_strip_order, std::max<size_t>(order.size(), 1) * sizeof(int)));
+            h->owned.push_back(h->d_strip_order);
+            HIPCHK(hipMemcpy(h->d_strip_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         if (h->world > 1) {
             h->recv.assign((size_t)h->recv_slots, nullptr);
             for (int b = 0; b < h->recv_slots; ++b)
@@ -719,9 +740,9 @@ extern "C" int ck_assemble_joint(ck_handle* h) {
         const bool fast = tables_usable(h) && attempt == 0;
         if (fast) next_worklist(h);   // a zeroed counter, without a memset launch in front of the assembly
         {
-            CkPanelMap pm{h->d_tile0, h->d_panel_of, h->d_sigptr, h->n_owned, nullptr, 0};
+            CkPanelMap pm{h->d_tile0, h->d_panel_of, h->d_sigptr, h->n_owned, nullptr, 0, h->d_strip_order};
             ck_launch_assemble_sigma(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, h->s0, h->su,
-                                     layout_of(h), pm, h->total_tiles, h->wl);
+                                     layout_of(h), pm, h->total_tiles, h->wl, fast ? h->assemble_queue : 0);
         }
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, false, h->d_blk, h->metric, 0, nullptr, 0, h->s0, layout_of(h), h->wl,
@@ -1552,7 +1573,8 @@ static int aux_begin_impl(ck_handle* h, int i, const double* pcoords, int64_t m,
         const bool fast = tables_usable(h) && attempt == 0;
         if (fast) next_worklist(h);
         ck_launch_assemble_aux(h->stream, fast, h->d_blk, h->d_tabs, h->d_coefptr, h->metric, i, h->p0, h->pu, m,
-                               mpad, h->s0, h->su, h->z, layout_of(h), h->nK, h->aux, h->wl, fast && fold ? h->d_pcoords : nullptr);
+                               mpad, h->s0, h->su, h->z, layout_of(h), h->nK, h->aux, h->wl, fast && fold ? h->d_pcoords : nullptr,
+                               fast ? h->assemble_queue : 0);
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, true, h->d_blk, h->metric, i, h->p0, mpad, h->s0, layout_of(h), h->wl,
                                h->d_sigptr, h->aux);
@@ -1767,9 +1789,9 @@ extern "C" int ck_verify_model(ck_handle* h, int64_t* info) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fast = tables_usable(h) && attempt == 0;
         if (fast) next_worklist(h);
-        CkPanelMap pm{h->d_sch_tile0, h->d_sch_panel_of, h->d_sch_ptr, nJ, nullptr, 0};
+        CkPanelMap pm{h->d_sch_tile0, h->d_sch_panel_of, h->d_sch_ptr, nJ, nullptr, 0, nullptr};
         ck_launch_assemble_sigma(h->stream, fast, h->d_sch_blk, h->d_sch_tabs, h->d_sch_coefptr, h->metric, h->sch_c,
-                                 h->sch_u, L, pm, h->sch_tiles, h->wl);
+                                 h->sch_u, L, pm, h->sch_tiles, h->wl, fast ? h->assemble_queue : 0);
         if (!fast) break;
         ck_launch_assemble_fix(h->stream, false, h->d_sch_blk, h->metric, 0, nullptr, 0, h->sch_c, L, h->wl, h->d_sch_ptr,
                                nullptr);
@@ -2825,6 +2847,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "group_first") || !strcmp(name, "group_tail") || !strcmp(name, "group_tail_panels")) {   // see group_plan()
         if (value < (strcmp(name, "group_first") ? 0 : -1) || value > 1024) return fail("group_first (-1 = automatic) / group_tail / group_tail_panels must be in [0, 1024]");
         (!strcmp(name, "group_first") ? h->group_first : !strcmp(name, "group_tail") ? h->group_tail : h->group_tail_panels) = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "assemble_queue")) {   // see ck_handle::assemble_queue
+        if (value < -1 || value > 4096) return fail("assemble_queue must be in [-1, 4096]");
+        h->assemble_queue = (int)value;
         return 0;
     }
     if (!strcmp(name, "local_left")) {   // see ck_handle::local_left

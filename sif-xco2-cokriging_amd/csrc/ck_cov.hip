@@ -261,26 +261,49 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
                                                                  CkPanelMap pm, CkWorklist wl,
                                                                  const double* __restrict__ raw = nullptr, long mpad = 0,
                                                                  double* __restrict__ pc_out = nullptr,
-                                                                 double* __restrict__ pu_out = nullptr) {
+                                                                 double* __restrict__ pu_out = nullptr,
+                                                                 unsigned* __restrict__ queue = nullptr, int n_strips = 0,
+                                                                 int csubs = CK_NB / 64) {
     __shared__ double lcoef[FAST ? (CK_TAB_DEG + 1) * CK_TAB_STRIDE : 1];
     __shared__ double srow[(FAST && AUX) ? 3 * 64 : 1];   // chord vectors of this strip's 64 rows (raw != nullptr)
+    __shared__ unsigned s_next;
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    // blockIdx.x enumerates the 64-row tiles of ALL panels of this launch; a workgroup walks the
+    int loaded = -1, tbase = 0;
+    unsigned tn = 1;
+    // Work units: chunks of csubs sub-tiles of a 64 x 512 strip.  queue == nullptr: one strip per workgroup (blockIdx.x).
+    // queue != nullptr (option "assemble_queue"): a resident set of workgroups takes chunks from a counter -- the first one by
+    // its own id, the next one fetched while the current one is computed -- so that the 48 KB table is loaded once per
+    // workgroup instead of once per strip and a small launch is balanced to a chunk, not to a strip.
+    const int per = (CK_NB / 64) / csubs;
+    const unsigned n_chunks = queue ? (unsigned)n_strips * (unsigned)per : gridDim.x;
+    unsigned cur = blockIdx.x;
+    while (cur < n_chunks) {
+    if (queue) {
+        __syncthreads();   // the previous chunk's readers of srow / s_next are done
+        if (t == 0) s_next = gridDim.x + atomicAdd(queue, 1u);
+    }
+    const unsigned strip = queue ? cur / (unsigned)per : cur;
+    const int sub_first = queue ? (int)(cur % (unsigned)per) * csubs : 0;
+    const unsigned n_all = queue ? (unsigned)n_strips : gridDim.x;
+    // `strip` enumerates the 64-row tiles of ALL panels of this launch; a workgroup walks the
     // eight 64 x 64 sub-tiles of its 64 x 512 strip
     long row0, col0;
     double* out;
     long tile;
     if (AUX) {   // every panel has mpad / 64 row tiles; row-tile-major, LAST row tile first: the tiles that hold the z row
                  // (and, with padding rows behind them, take the edge path) are dispatched first instead of forming the tail
-        const long tr = blockIdx.x / pm.n_panels;
-        const long j = blockIdx.x - tr * pm.n_panels;
+        // (work-queue form: block column OUTER, so that the chunks a workgroup takes one after the other -- ids a grid apart --
+        // walk through the block columns once and with them through the Matern blocks: the 48 KB table is reloaded twice, not
+        // at every other chunk)
+        const long tr = queue ? strip % pm.aux_tiles : strip / pm.n_panels;
+        const long j = queue ? strip / pm.aux_tiles : strip - tr * pm.n_panels;
         tile = pm.aux_tiles - 1 - tr;
         row0 = 0;
         col0 = j * CK_NB;
         out = pm.aux + j * pm.aux_tiles * 64 * CK_NB;
     } else {     // owned panels, sizes differ: tile0[j] = first tile of the j-th owned panel.  Dispatched back to front: the
                  // last panels are short and mostly padding (edge path), the launch should not end on them
-        const int bid = (int)(gridDim.x - 1 - blockIdx.x);
+        const int bid = (queue && pm.order) ? pm.order[strip] : (int)(n_all - 1 - strip);
         int j = 0;
         while (j + 1 < pm.n_panels && pm.tile0[j + 1] <= bid) ++j;
         const int K = pm.panel_of[j];
@@ -329,9 +352,7 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
             ru2[a] = FAST ? R.u2[r] : 0.0;
         }
     }
-    int loaded = -1, tbase = 0;
-    unsigned tn = 1;
-    for (int sub = 0; sub < CK_NB / 64; ++sub) {
+    for (int sub = sub_first; sub < sub_first + csubs; ++sub) {
         const long ct = col0 + sub * 64;
         const int pc = (int)(ct >= L.n0p);
         const int bidx = pr + pc;
@@ -360,6 +381,10 @@ __global__ __launch_bounds__(256, FAST ? 3 : 1) void k_assemble(const CkMatern* 
         if (FAST && __builtin_amdgcn_ballot_w64(slowmask != 0u) != 0ULL)   // rare: hand the pairs to the exact pass
             worklist_append(wl, slowmask, (int)(rt + ty), 16, (int)(ct + 2 * tx));
     }
+    if (!queue) break;
+    __syncthreads();
+    cur = s_next;
+    }
 }
 
 // Exact evaluation of the worklist entries (see assemble_subtile).  Sigma: entry (r, c) lives in panel
@@ -370,7 +395,10 @@ __global__ __launch_bounds__(256) void k_assemble_fix(const CkMatern* __restrict
                                                        double* const* __restrict__ sigptr, double* __restrict__ aux,
                                                        long mpad) {
     const unsigned n = *wl.count < wl.cap ? *wl.count : wl.cap;
-    if (wl.reset && blockIdx.x == 0 && threadIdx.x == 0) *wl.reset = 0u;   // the next assembly's counter (not read by this launch)
+    if (wl.reset && blockIdx.x == 0 && threadIdx.x == 0) {   // the next assembly's counters (not read by this launch)
+        wl.reset[0] = 0u;   // its worklist count
+        wl.reset[1] = 0u;   // its work queue (k_assemble, option "assemble_queue")
+    }
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int2 it = wl.items[e];
         const long r = it.x, c = it.y;
@@ -389,12 +417,23 @@ __global__ __launch_bounds__(256) void k_assemble_fix(const CkMatern* __restrict
 // all owned Sigma panels in one launch
 void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
                               const double* const* coefs, int metric, const double* c, const double* u, CkLayout L,
-                              CkPanelMap pm, int total_tiles, CkWorklist wl) {
+                              CkPanelMap pm, int total_tiles, CkWorklist wl, int queue_slots) {
     if (total_tiles <= 0) return;
     const int64_t np = L.npad;
     CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
     dim3 grid((unsigned)total_tiles);
-    if (fast)
+    // automatic (-1): 768 resident workgroups (three per CU) from 8 strips per workgroup on.  Measured (scripts/ab_assembly.py): at
+    // N = 40 000 K1 1.31 -> 1.27 ms, K2 0.61 -> 0.56 ms (the table is loaded once per workgroup, the launch is balanced to a chunk);
+    // at N = 10 000, where a chunk would have to be a quarter strip, the per-chunk latencies cost more than the balance buys
+    // (K1 0.13 -> 0.185 ms): small launches keep one strip per workgroup.
+    if (queue_slots < 0) queue_slots = total_tiles >= 8 * 768 ? 768 : 0;
+    if (fast && queue_slots > 0) {
+        // a resident set of workgroups on a work queue (wl.count + 1); small launches are balanced in half or quarter strips
+        const int csubs = total_tiles >= 16 * queue_slots ? 8 : (total_tiles >= 4 * queue_slots ? 4 : 2);
+        const long chunks = (long)total_tiles * (8 / csubs);
+        k_assemble<true, false><<<dim3((unsigned)std::min<long>(chunks, queue_slots)), dim3(256), 0, s>>>(
+            blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, pm, wl, nullptr, 0, nullptr, nullptr, wl.count + 1, total_tiles, csubs);
+    } else if (fast)
         k_assemble<true, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, pm, wl);
     else
         k_assemble<false, false><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, 0, S, 0, S, nullptr, L, pm, wl);
@@ -404,14 +443,21 @@ void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, con
 void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
                             const double* const* coefs, int metric, int i_pred, double* pc, double* pu,
                             int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
-                            int n_panels, double* aux, CkWorklist wl, const double* raw) {
+                            int n_panels, double* aux, CkWorklist wl, const double* raw, int queue_slots) {
     if (mpad <= 0 || n_panels <= 0) return;
     const int64_t np = L.npad;
     CkSiteRef P{pc, pc + mpad, pc + 2 * mpad, pu, pu + mpad, pu + 2 * mpad};
     CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
-    CkPanelMap pm{nullptr, nullptr, nullptr, n_panels, aux, (long)(mpad / 64)};
+    CkPanelMap pm{nullptr, nullptr, nullptr, n_panels, aux, (long)(mpad / 64), nullptr};
     dim3 grid((unsigned)(n_panels * (mpad / 64)));
-    if (fast)
+    if (queue_slots < 0) queue_slots = (long)n_panels * (mpad / 64) >= 8 * 768 ? 768 : 0;
+    if (fast && queue_slots > 0) {
+        const long strips = (long)n_panels * (mpad / 64);
+        const int csubs = strips >= 16 * queue_slots ? 8 : (strips >= 4 * queue_slots ? 4 : 2);
+        const long chunks = strips * (8 / csubs);
+        k_assemble<true, true><<<dim3((unsigned)std::min<long>(chunks, queue_slots)), dim3(256), 0, s>>>(
+            blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl, raw, (long)mpad, pc, pu, wl.count + 1, (int)strips, csubs);
+    } else if (fast)
         k_assemble<true, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl, raw, (long)mpad, pc, pu);
     else
         k_assemble<false, true><<<grid, dim3(256), 0, s>>>(blk, tabs, coefs, metric, i_pred, P, m, S, z, L, pm, wl);

@@ -33,9 +33,9 @@ struct CkLayout {
 // of the NEXT assembly, so that no assembly starts with a memset launch of its own.
 struct CkWorklist {
     int2* items;
-    unsigned* count;
+    unsigned* count;   // count[0]: deferred entries; count[1]: work queue of the assembly kernel (option "assemble_queue")
     unsigned cap;
-    unsigned* reset;   // the other counter (may be null)
+    unsigned* reset;   // the other pair of counters (may be null)
 };
 // which panels one assembly launch covers: Sigma -- the owned panels (tile0[j] = index of the first
 // 64-row tile of the j-th owned panel, panel_of[j] = its block column, sigptr[K] = its storage);
@@ -47,12 +47,14 @@ struct CkPanelMap {
     int n_panels;
     double* aux;
     long aux_tiles;
+    const int* order;   // Sigma, work-queue form: the strips sorted by Matern block (may be null: back to front)
 };
 // Sigma: every owned block column (rows K*NB.., ld = CK_NB) in ONE launch.
 // c: 3 x npad exact-formula coordinates, u: 3 x npad chord vectors.  fast: table path.
 void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
                               const double* const* coefs, int metric, const double* c, const double* u, CkLayout L,
-                              CkPanelMap pm, int total_tiles, CkWorklist wl);
+                              CkPanelMap pm, int total_tiles, CkWorklist wl, int queue_slots = 0 /* > 0 (table path): that many
+                              resident workgroups take their strips from a work queue (the word behind wl.count, zero at launch) */);
 // right-hand-side rows, every block column in one launch: rows = prediction sites p in [0, m)
 // (row m = data values z, rows > m zero), cols = data sites.
 // raw (table path only; may be null): the prediction sites' coordinates as the caller gave them (m x 2, padded with zeros
@@ -61,7 +63,7 @@ void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, con
 void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const CkTable* tabs,
                             const double* const* coefs, int metric, int i_pred, double* pc, double* pu,
                             int64_t m, int64_t mpad, const double* c, const double* u, const double* z, CkLayout L,
-                            int n_panels, double* aux, CkWorklist wl, const double* raw = nullptr);
+                            int n_panels, double* aux, CkWorklist wl, const double* raw = nullptr, int queue_slots = 0);
 // evaluate the deferred entries of the preceding table-path launches (no-op when the list is empty)
 void ck_launch_assemble_fix(hipStream_t s, bool aux_rows, const CkMatern* blk, int metric, int i_pred,
                             const double* pc, int64_t mpad, const double* c, CkLayout L, CkWorklist wl,
