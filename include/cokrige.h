@@ -361,9 +361,9 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * the look-ahead of "fused_la" -- instead of a factorisation and a substitution sweep that share the chip on two streams
  * (same bits either way);
  * "assemble_queue" (-1 automatic, 0 off, else the number of workgroups): the table-path assembly kernels as a resident set of
- * workgroups that take their 64 x 512 strips (or halves / quarters of them) from a work queue, strips sorted by Matern block -- the
- * 48 KB table is loaded once per workgroup instead of once per strip; automatic: 768 workgroups from 8 strips per workgroup on
- * (N = 40 000: K1 1.31 -> 1.27 ms, K2 0.61 -> 0.56 ms; smaller launches keep one strip per workgroup);
+ * workgroups that take their 64 x 512 strips (or halves / quarters of them) from a work queue -- the 48 KB table is loaded once per
+ * workgroup instead of once per strip; automatic: the right-hand-side assembly (K2) with 768 workgroups from 8 strips per workgroup
+ * on (N = 40 000: 0.62 -> 0.56 ms), Sigma (K1) never (faster on one box, slower on another);
  * "local_slab_mb" = scratch budget of ck_predict_local in MiB (0, default: a quarter of the free memory, at most
  * 32 GiB; the points are processed in batches that fit; the scratch is kept until ck_destroy and reused);
  * "local_tile_min" (default 64 = the LDS kernel's limit): neighbourhoods with more sites than this are factored by

@@ -422,11 +422,10 @@ void ck_launch_assemble_sigma(hipStream_t s, bool fast, const CkMatern* blk, con
     const int64_t np = L.npad;
     CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
     dim3 grid((unsigned)total_tiles);
-    // automatic (-1): 768 resident workgroups (three per CU) from 8 strips per workgroup on.  Measured (scripts/ab_assembly.py): at
-    // N = 40 000 K1 1.31 -> 1.27 ms, K2 0.61 -> 0.56 ms (the table is loaded once per workgroup, the launch is balanced to a chunk);
-    // at N = 10 000, where a chunk would have to be a quarter strip, the per-chunk latencies cost more than the balance buys
-    // (K1 0.13 -> 0.185 ms): small launches keep one strip per workgroup.
-    if (queue_slots < 0) queue_slots = total_tiles >= 8 * 768 ? 768 : 0;
+    // automatic (-1): OFF for Sigma.  Measured (scripts/ab_assembly.py, and bench.py with CK_BENCH_OPTIONS=assemble_queue=...): the
+    // work-queue form of K1 is 3 % faster in isolation on one box (1.31 -> 1.27 ms) and 7 % slower inside the bench's steps on
+    // another (1.266 -> 1.354 ms) -- not a robust gain; K2's is (right-hand sides below).  An explicit number still selects it.
+    if (queue_slots < 0) queue_slots = 0;
     if (fast && queue_slots > 0) {
         // a resident set of workgroups on a work queue (wl.count + 1); small launches are balanced in half or quarter strips
         const int csubs = total_tiles >= 16 * queue_slots ? 8 : (total_tiles >= 4 * queue_slots ? 4 : 2);
@@ -450,6 +449,10 @@ void ck_launch_assemble_aux(hipStream_t s, bool fast, const CkMatern* blk, const
     CkSiteRef S{c, c + np, c + 2 * np, u, u + np, u + 2 * np};
     CkPanelMap pm{nullptr, nullptr, nullptr, n_panels, aux, (long)(mpad / 64), nullptr};
     dim3 grid((unsigned)(n_panels * (mpad / 64)));
+    // automatic (-1): 768 resident workgroups (three per CU) on a work queue from 8 strips per workgroup on: the 48 KB table is
+    // loaded once per workgroup instead of once per strip and the launch is balanced to half a strip.  N = 40 000: K2 0.605 -> 0.56 ms
+    // in isolation, 0.618 -> 0.561 ms inside the bench's steps (two boxes); at N = 10 000, where a chunk would have to be a quarter
+    // strip, the per-chunk latencies cost what the balance buys: small launches keep one strip per workgroup.
     if (queue_slots < 0) queue_slots = (long)n_panels * (mpad / 64) >= 8 * 768 ? 768 : 0;
     if (fast && queue_slots > 0) {
         const long strips = (long)n_panels * (mpad / 64);
