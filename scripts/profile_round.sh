@@ -26,7 +26,7 @@ python3 bench.py --steps 10 --warmup 3 > gpurun_out/prof_${TAG}_bench_line.json 
 python3 bench.py --config 1 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench_config1.json 2>/dev/null
 python3 bench.py --n-obs 50000 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench_n50k.json 2>/dev/null
 python3 scripts/ab_tall.py 20000 3 plain,two,tall,tallG2,tallG4,tallG4F2,tallF1T 2>/dev/null | grep "^N=" > gpurun_out/prof_${TAG}_tall_ab.txt
-python3 scripts/ab_tall.py 5000 3 plain,two,tall,tallG2 x 1 2>/dev/null | grep "^N=" >> gpurun_out/prof_${TAG}_tall_ab.txt
+python3 scripts/ab_tall.py 5000 3 plain,two,tall,tallG2 1 2>/dev/null | grep "^N=" >> gpurun_out/prof_${TAG}_tall_ab.txt
 python3 scripts/bench_variogram.py 1000000 > gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
 python3 scripts/bench_variogram.py 1000000 cross cpu >> gpurun_out/prof_${TAG}_vario_1M.json 2>/dev/null
 python3 scripts/bench_local.py 20000 50 100 200 400 600 > gpurun_out/prof_${TAG}_local.json 2>/dev/null

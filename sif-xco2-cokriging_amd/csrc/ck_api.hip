@@ -177,6 +177,10 @@ struct ck_handle {
     int assemble_queue = -1;          // option "assemble_queue": resident workgroups of the table-path assembly kernels on a work queue
                                       // (-1 automatic: 768 from 8 strips per workgroup on; 0 = one strip per workgroup)
     int tall_sweep = 1;               // ck_factor_predict: ONE sweep over the tall matrix [Sigma; c0^T; z^T] (tall_sweeps, round 4)
+    int tall_split = 2;               // tall sweep, panel steps hidden under a bulk update: cooperative launch on the 512 x 512 head only,
+                                      // every other row (Sigma's and the right-hand sides') through k_panel_rows_all (0: never, 1: every
+                                      // panel, 2: panels behind the first group with at least tall_split_rows rows)
+    int tall_split_rows = 24 * CK_NB; // tall_split 2: shorter panels keep the one cooperative launch
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
@@ -874,7 +878,10 @@ static void syrk_update(ck_handle* h, hipStream_t st, int K0, int np, int J0, in
 
 // with_aux (the tall sweep, cooperative panel step only): the right-hand-side rows of block column K walk through the panel as
 // further workgroups of the same launch
-static void panel_factor_on(ck_handle* h, int K, hipStream_t st, bool with_aux = false) {
+// split (with_aux only): the cooperative launch on the 512 x 512 head alone, then every row below it and every right-hand-side row
+// through k_panel_rows_all -- a chunk below the head spins until the head's chunks have published, and while it spins it holds a
+// slot the bulk update running beside the chain would use; k_panel_rows_all's workgroups wait for nobody (same arithmetic per row).
+static void panel_factor_on(ck_handle* h, int K, hipStream_t st, bool with_aux = false, bool split = false) {
     double* P = h->sig[K];
     const int64_t R = h->Npad - (int64_t)K * CK_NB;
     double* tail = P + R * CK_NB;   // inverses of the eight diagonal blocks (CK_PANEL_TAIL)
@@ -887,8 +894,15 @@ static void panel_factor_on(ck_handle* h, int K, hipStream_t st, bool with_aux =
             drop = 3;
             h->coop_inject_panel = -1;
         }
-        ck_launch_panel_coop(st, P, R, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16,
-                             with_aux ? h->aux + (int64_t)K * h->mpad * CK_NB : nullptr, with_aux ? h->mpad : 0, h->coop_spins, drop);
+        double* X = with_aux ? h->aux + (int64_t)K * h->mpad * CK_NB : nullptr;
+        if (split && with_aux && R > CK_NB) {
+            ck_launch_panel_coop(st, P, CK_NB, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16, nullptr, 0,
+                                 h->coop_spins, drop);
+            ck_launch_panel_rows_all(st, P + (int64_t)CK_NB * CK_NB, R - CK_NB, P, tail, X, h->mpad);
+            return;
+        }
+        ck_launch_panel_coop(st, P, R, tail, (int64_t)K * CK_NB, h->d_info, h->d_coop, h->coop_seq, h->d_coop + 16, X, with_aux ? h->mpad : 0,
+                             h->coop_spins, drop);
         return;
     }
     if (h->panel_fused & 4) {
@@ -1112,7 +1126,9 @@ extern "C" int ck_factor_info(ck_handle* h, int64_t* info) {
 
 // automatic: 4 from 40 panels on (round 4; 3 in rounds 1-3: interleaved A/B at N = 40 000, G = 3 / 4 / 5 / 6 with their best first
 // groups: 491.0 / 488.2 / 489.5 / 489.2 ms), 1 below
-static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 4 : 1); }
+// automatic group size (measured with scripts/ab_tall.py, round 4: groups of two pay from 14 panels -- N = 10 000: 23.2 -> 22.4 ms --,
+// groups of four from 40)
+static int eff_group(const ck_handle* h) { return h->panel_group > 0 ? h->panel_group : (h->nK >= 40 ? 4 : h->nK >= 14 ? 2 : 1); }
 
 // Group boundaries of the single-process sweeps (every form -- ck_factor / ck_predict, the two overlapped sweeps, the tall
 // sweep -- takes them from here).  The grouping does not touch the results: an element's updates are accumulated k ascending inside
@@ -1374,7 +1390,11 @@ static int tall_sweeps(ck_handle* h) {
         const int K0 = first(g), Gc = count(g);
         for (int q = 0; q < Gc; ++q) {
             if (q > 0) update(C, K0, q, K0 + q, 1);
-            panel_factor_on(h, K0 + q, C, true);
+            const int K = K0 + q;
+            const int64_t R = h->Npad - (int64_t)K * CK_NB;
+            // panel steps that run under a bulk update and have many chunks: the head cooperatively, the rows on their own
+            const bool split = h->tall_split == 1 || (h->tall_split == 2 && g >= 1 && R >= h->tall_split_rows);
+            panel_factor_on(h, K, C, true, split);
         }
         HIPCHK(hipEventRecord(h->ev_pan[g], C));   // group g's panels and right-hand-side block columns are final
         if (g + 1 < ng) {
@@ -2857,6 +2877,16 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "local_left")) {   // see ck_handle::local_left
         if (value < 0 || value > 1) return fail("local_left must be 0 or 1");
         h->local_left = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "tall_split")) {
+        if (value < 0 || value > 2) return fail("tall_split must be 0, 1 or 2");
+        h->tall_split = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "tall_split_rows")) {
+        if (value < 0) return fail("tall_split_rows must be >= 0");
+        h->tall_split_rows = (int)std::min<int64_t>(value, 1 << 30);
         return 0;
     }
     if (!strcmp(name, "tall_sweep")) {   // see ck_handle::tall_sweep

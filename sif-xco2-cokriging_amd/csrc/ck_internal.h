@@ -119,7 +119,8 @@ void ck_launch_potrf64_prof(hipStream_t s, double* A, int64_t ld, long long* inf
 // X L^T = A in place for `nrows` rows of A (ld), 64 columns; L (64 x 64 lower, ldl).  nrows % 64 == 0.
 // fused panel step (ck_la.hip, option "panel_fused")
 void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv);
-void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail);
+void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail, double* X2 = nullptr,
+                              int64_t nrows2 = 0);
 void ck_launch_panel_rows(hipStream_t s, double* X, int64_t row_first, int64_t nrows, const double* P, int j,
                           const double* Linv);
 void ck_launch_trsm64(hipStream_t s, double* A, int64_t ld, int64_t nrows, const double* Linv);

@@ -1317,17 +1317,19 @@ __global__ __launch_bounds__(256, 2) void k_panel_rows(double* X, long row_first
 // all eight sub-blocks of a panel for 64 right-hand-side rows: those rows depend on nothing but the factored
 // panel, so one workgroup can walk through the panel on its own (one launch per panel instead of eight).
 // tail: the eight 64 x 64 inverses behind the panel's rows.
-__global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const double* P, const double* tail) {
+// X2 / n1: chunks n1, n1 + 1, .. are rows of a second array (the tall sweep's split panel step: the panel's rows below the head
+// and the right-hand-side rows of the block column in one launch)
+__global__ __launch_bounds__(256, 2) void k_panel_rows_all(double* X, const double* P, const double* tail, double* X2, int n1) {
     __shared__ __attribute__((aligned(16))) double As[64 * 66];
     __shared__ __attribute__((aligned(16))) double Bs[64 * 66];
-    const long row0 = 64 * (long)blockIdx.x;
+    const int b = (int)blockIdx.x;
+    double* rows = b < n1 ? X + 64L * b * CK_NB : X2 + 64L * (b - n1) * CK_NB;
     for (int j = 0; j < CK_NB / 64; ++j) {
         if (j) {   // sub-block j reads what other threads of this workgroup stored in sub-blocks < j
             __threadfence_block();
             __syncthreads();
         }
-        lt_rows_body<true>(X + row0 * CK_NB + 64 * j, X + row0 * CK_NB, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j,
-                           tail + (long)j * 64 * 64, As, Bs);
+        lt_rows_body<true>(rows + 64 * j, rows, CK_NB, P + (long)(64 * j) * CK_NB, CK_NB, j, tail + (long)j * 64 * 64, As, Bs);
     }
 }
 
@@ -1626,9 +1628,11 @@ void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail,
                                                                               (int)(nrows / 64), spins, drop);
 }
 
-void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail) {
-    if (nrows <= 0) return;
-    k_panel_rows_all<<<dim3((unsigned)(nrows / 64)), dim3(256), 0, s>>>(X, P, tail);
+void ck_launch_panel_rows_all(hipStream_t s, double* X, int64_t nrows, const double* P, const double* tail, double* X2,
+                              int64_t nrows2) {
+    if (!X2) nrows2 = 0;
+    if (nrows + nrows2 <= 0) return;
+    k_panel_rows_all<<<dim3((unsigned)((nrows + nrows2) / 64)), dim3(256), 0, s>>>(X, P, tail, X2, (int)(nrows / 64));
 }
 
 void ck_launch_panel_diag(hipStream_t s, double* P, int j, int64_t g0, long long* info, double* Linv) {

@@ -631,7 +631,7 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     assert np.array_equal(pred, ref[0]) and np.array_equal(err, ref[1])
     t = h2.timings()
     assert t["fused_sweeps_ms"] > 0 and t["panel_coop_redone"] == 0
-    G = group if group else 1                   # automatic: 1 below 40 panels
+    G = group if group else 1                   # automatic: 1 below 14 panels, 2 below 40, 4 from there
     ng = -(-11 // G)
     launches = sum(min(G, 11 - g * G) - 1 for g in range(ng)) + sum(1 for g in range(ng) for d in (1, 2, 3) if g + d < ng)
     assert t["syrk_launches"] == launches, (t["syrk_launches"], launches)
@@ -642,6 +642,16 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     h3.set_option("fused_group", group)
     info, p3, e3 = h3.factor_predict(1, pc)
     assert info == 0 and np.array_equal(p3, ref[0]) and np.array_equal(e3, ref[1])
+    # the split panel step (option tall_split; automatic from 12 288 rows behind the first group): the cooperative launch on the
+    # 512 x 512 head only, every other row -- Sigma's and the right-hand sides' -- through k_panel_rows_all in one launch
+    for split, rows in ((1, 0), (2, 1024), (0, 0)):
+        h4, _ = _assembled(native, params, coords, values, HAV)
+        h4.set_option("fused_group", group)
+        h4.set_option("tall_split", split)
+        h4.set_option("tall_split_rows", rows)
+        info, p4, e4 = h4.factor_predict(1, pc)
+        assert info == 0 and np.array_equal(p4, ref[0]) and np.array_equal(e4, ref[1]), (split, rows)
+        assert h4.timings()["panel_coop_redone"] == 0
 
 
 @pytest.mark.parametrize("m", [100, 982])
@@ -675,7 +685,7 @@ def test_right_hand_side_assembly_transforms_its_own_sites_and_reads_nothing_sta
     assert info == 0 and np.array_equal(p, fresh[2][0]) and np.array_equal(e, fresh[2][1])
 
 
-@pytest.mark.parametrize("entry", ["factor", "factor_predict", "factor_predict_two_sweeps"])
+@pytest.mark.parametrize("entry", ["factor", "factor_predict", "factor_predict_split", "factor_predict_two_sweeps"])
 def test_cooperative_panel_step_timeout_is_detected_and_the_factorisation_redone(native, entry):
     """k_panel_coop's safety net: option coop_inject_panel makes one workgroup of the diagonal block
     skip its flag store, so the bounded waits of the chunks below it trip, the error word is set, and the host must notice,
@@ -701,6 +711,8 @@ def test_cooperative_panel_step_timeout_is_detected_and_the_factorisation_redone
     else:
         if entry.endswith("two_sweeps"):
             h.set_option("tall_sweep", 0)
+        if entry.endswith("split"):                 # the cooperative launch on the head only (large panels take this form)
+            h.set_option("tall_split", 1)
         info, *got = h.factor_predict(0, pc)
         assert info == 0
         assert h.timings()["panel_coop_redone"] == 1
