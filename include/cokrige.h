@@ -360,6 +360,12 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * rows are further workgroups of the cooperative panel step and further tiles of every update launch (k_tall_group_d), with
  * the look-ahead of "fused_la" -- instead of a factorisation and a substitution sweep that share the chip on two streams
  * (same bits either way);
+ * "tall_split" (0 never / 1 every panel / 2 automatic, the default) and "tall_split_rows" (default 12 288): in the tall sweep the panel
+ * steps of panels behind the first group with at least that many rows run as the cooperative launch on the 512 x 512 head only plus
+ * ONE launch of k_panel_rows_all for every other row of the panel and of the right-hand sides -- no workgroup holds a slot while it
+ * waits for the head (same bits; N = 40 000: 0.5 % faster);
+ * "tall_thin" (0/1, default 1): a last right-hand-side tile row with at most 16 rows in front of the padding (m + 1 = 8 834: two rows)
+ * computes those rows' 16-row block only (same bits, 0.35 % at N = 40 000);
  * "assemble_queue" (-1 automatic, 0 off, else the number of workgroups): the table-path assembly kernels as a resident set of
  * workgroups that take their 64 x 512 strips (or halves / quarters of them) from a work queue -- the 48 KB table is loaded once per
  * workgroup instead of once per strip; automatic: the right-hand-side assembly (K2) with 768 workgroups from 8 strips per workgroup

@@ -181,6 +181,7 @@ struct ck_handle {
                                       // every other row (Sigma's and the right-hand sides') through k_panel_rows_all (0: never, 1: every
                                       // panel, 2: panels behind the first group with at least tall_split_rows rows)
     int tall_split_rows = 24 * CK_NB; // tall_split 2: shorter panels keep the one cooperative launch
+    int tall_thin = 1;                // tall sweep: a last right-hand-side tile row with <= 16 rows in front of the padding computes those only
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
     std::vector<hipEvent_t> ev_col, ev_pan;   // [K]: column K fully updated | panel K done
@@ -277,8 +278,7 @@ extern "C" int ck_create(int device_id, ck_handle** out) {
     HIPCHK(hipMalloc((void**)&h->d_coop, 32 * sizeof(unsigned)));
     HIPCHK(hipMemset(h->d_coop, 0, 32 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&h->d_blk, 3 * sizeof(CkMatern)));
-    HIPCHK(hipMalloc((void**)&h->d_info, sizeof(long long)));
-    HIPCHK(hipMemset(h->d_info, 0, sizeof(long long)));
+    h->d_info = (long long*)(h->d_coop + 18);   // behind the cooperative step's error word: one 16-byte read-back for both
     *out = h;
     return 0;
 }
@@ -302,7 +302,6 @@ extern "C" int ck_destroy(ck_handle* h) {
     schur_free(h);
     for (void* p : h->owned) (void)hipFree(p);
     (void)hipFree(h->d_blk);
-    (void)hipFree(h->d_info);
     if (h->d_tile0) (void)hipFree(h->d_tile0);
     if (h->local_slab) (void)hipFree(h->local_slab);
     if (h->d_panel_of) (void)hipFree(h->d_panel_of);
@@ -1380,7 +1379,7 @@ static int tall_sweeps(ck_handle* h) {
     auto update = [&](hipStream_t st, int K0, int np, int J0, int nJ) {
         if (nJ <= 0) return;
         gemm_timed_begin(h, st);
-        ck_launch_tall_group(st, h->d_sigptr, h->aux, h->mpad, K0, np, J0, nJ, h->nend);
+        ck_launch_tall_group(st, h->d_sigptr, h->aux, h->mpad, K0, np, J0, nJ, h->nend, h->tall_thin ? h->m + 1 : 0);
         gemm_timed_end(h, st);
     };
     HIPCHK(hipEventRecord(h->ev0, M));
@@ -1441,9 +1440,11 @@ extern "C" int ck_factor_predict(ck_handle* h, int i, const double* pcoords, int
     const bool la = h->fused_la >= 0 ? h->fused_la != 0 : h->nK >= 40;
     const bool tall = (h->panel_fused & 16) && h->tall_sweep != 0;
     if (tall ? tall_sweeps(h) : la ? fused_sweeps_la(h) : fused_sweeps(h)) return -1;
-    if (factor_info_raw(h, info)) return -1;
-    unsigned werr = 0;
-    HIPCHK(hipMemcpy(&werr, h->d_coop + 16, sizeof(werr), hipMemcpyDeviceToHost));
+    struct { unsigned werr, pad; long long info; } status = {0u, 0u, 0};   // d_coop[16 .. 19]: the error word and the info word
+    HIPCHK(hipMemcpyAsync(&status, h->d_coop + 16, sizeof(status), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *info = external_index(h, (int64_t)status.info);
+    const unsigned werr = status.werr;
     if (*info != 0 || werr != 0) {
         // not positive definite, or a cooperative panel step timed out: ck_factor's own handling (redo in the caller's
         // order for numpy's minor index / without the cooperative step), then the substitution on the finished factor.
@@ -2882,6 +2883,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "tall_split")) {
         if (value < 0 || value > 2) return fail("tall_split must be 0, 1 or 2");
         h->tall_split = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "tall_thin")) {
+        if (value < 0 || value > 1) return fail("tall_thin must be 0 or 1");
+        h->tall_thin = (int)value;
         return 0;
     }
     if (!strcmp(name, "tall_split_rows")) {

@@ -100,7 +100,7 @@ void ck_launch_panel_coop(hipStream_t s, double* P, int64_t nrows, double* tail,
 // one update of the TALL matrix [Sigma; c0^T; z^T]: block columns J0 .. J0 + nJ - 1 of Sigma and of the mpad right-hand-side
 // rows by the panels K0 .. K0 + np - 1, one launch (ck_la.hip: k_tall_group_d)
 void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux, int64_t mpad, int K0, int np, int J0, int nJ,
-                          int64_t nvalid);
+                          int64_t nvalid, int64_t mrows = 0);
 // diagnostic: the cooperative panel step with shader-clock stamps of its links 1 .. 7 (prof: 64 words)
 void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
                                unsigned* flags, unsigned seq, unsigned* err, long long* prof);

@@ -398,10 +398,14 @@ struct CkSrcAux {
 // -10 ms in the factorisation and -8 ms in the solve sweep at N = 40 000.  Tile structures measured and retired
 // (DESIGN.md section 5 keeps their numbers): 4 waves of 64 x 64 (register- and DMA-staged), 128 x 64 tiles with
 // three workgroups per CU, one 256 x 128 workgroup per CU, padded LDS rows, a ping-pong schedule.
-template <int WAVES, class SRC>
+// NI: 16-row blocks this WAVE computes (4: all of its 64 rows).  A right-hand-side tile row that holds only a few rows in front of
+// the padding (m + 1 = 8 834 rows: 69 tile rows and two rows) runs with NI = 1 in the waves of the upper half and NI = 0 -- staging
+// and barriers only -- in the others (k_tall_group_d): an eighth of a tile's MFMAs; a row's result does not depend on its neighbours.
+template <int WAVES, class SRC, int NI = 4>
 __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, const SRC& src, int np, long r0, long c0,
                                             char* lds) {
     static_assert(WAVES == 8, "8 waves of 64 x 32");
+    constexpr int NA = NI > 0 ? NI : 1;
     constexpr int BOFF = 128 * 128;
     constexpr int STAGE = 256 * 128;
     constexpr int NST = CK_NB / GEMM_BK;
@@ -456,9 +460,9 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, lp_, 16, (int)vo4[3], (int)(kbyte_), 3072, 0);            \
     }
     CK_DMA_CHUNK(0, 0L);
-    d4_t acc[4][WJ];
+    d4_t acc[NA][WJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const ck_gchar* rowp = reinterpret_cast<const ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);   // wave-uniform
@@ -492,24 +496,26 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
     // since this chunk's barrier) in front of the second half's -- so that no LDS round trip is exposed.  (Tried in round 3's
     // first session with the barrier in mid-chunk: 3 % slower then, with ten vector instructions still in the loop; now
     // trailing updates 287.8 -> 285.8 ms per factorisation.)
-    d2_t af0[4], bf0[WJ], af1[4], bf1[WJ];
+    d2_t af0[NA], bf0[WJ], af1[NA], bf1[WJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af0[i] = *reinterpret_cast<const d2_t*>(lds + a_rd[0] + i * 2048);
+    for (int i = 0; i < NI; ++i) af0[i] = *reinterpret_cast<const d2_t*>(lds + a_rd[0] + i * 2048);
+    if (NI > 0)
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(lds + b_rd[0] + j * 2048);
+        for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(lds + b_rd[0] + j * 2048);
     auto step = [&](auto cur_c, int st) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_c)::value;
         const char* sb = lds + cur * STAGE;
         const char* sn = lds + (cur ^ 1) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af1[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[1] + i * 2048);
+        for (int i = 0; i < NI; ++i) af1[i] = *reinterpret_cast<const d2_t*>(sb + a_rd[1] + i * 2048);
+        if (NI > 0)
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) bf1[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[1] + j * 2048);
+            for (int j = 0; j < WJ; ++j) bf1[j] = *reinterpret_cast<const d2_t*>(sb + b_rd[1] + j * 2048);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i][h], bf0[j][h], acc[i][j], 0, 0, 0);
@@ -519,15 +525,16 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
         if (st + 2 < nst) CK_DMA_NEXT(cur);
         if (st + 1 < nst) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af0[i] = *reinterpret_cast<const d2_t*>(sn + a_rd[0] + i * 2048);
+            for (int i = 0; i < NI; ++i) af0[i] = *reinterpret_cast<const d2_t*>(sn + a_rd[0] + i * 2048);
+            if (NI > 0)
 #pragma unroll
-            for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(sn + b_rd[0] + j * 2048);
+                for (int j = 0; j < WJ; ++j) bf0[j] = *reinterpret_cast<const d2_t*>(sn + b_rd[0] + j * 2048);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i][h], bf1[j][h], acc[i][j], 0, 0, 0);
@@ -539,7 +546,7 @@ __device__ __forceinline__ void gemm_tile_d(double* __restrict__ C, long ldc, co
 #undef CK_DMA_NEXT
 #undef CK_DMA_CHUNK
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ck_gchar* rowp = reinterpret_cast<ck_gchar*>(Cb + (long)(i * 16 + 4 * r) * ldc);
@@ -626,8 +633,9 @@ struct CkSrcTall {
     }
 };
 
+// thin_tm: the right-hand-side tile row with at most 16 rows in front of the padding (-1: none) -- gemm_tile_d's NI
 __global__ __launch_bounds__(512, 4) void k_tall_group_d(double* const* __restrict__ sigptr, double* __restrict__ aux, long mpad,
-                                                          int K0, int np, const CkTileMap map) {
+                                                          int K0, int np, const CkTileMap map, int thin_tm) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     int u, tm, tn;
     const bool ax = ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
@@ -635,17 +643,25 @@ __global__ __launch_bounds__(512, 4) void k_tall_group_d(double* const* __restri
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     const CkSrcTall src{sigptr, aux, mpad, K0, J, r0, c0, ax};
     double* C = ax ? aux + (long)J * mpad * CK_NB : sigptr[J];
-    gemm_tile_d<8>(C, CK_NB, src, np, r0, c0, lds);
+    if (!(ax && tm == thin_tm)) {
+        gemm_tile_d<8>(C, CK_NB, src, np, r0, c0, lds);
+    } else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) {   // the waves of rows 0 .. 63: their first 16-row block
+        gemm_tile_d<8, CkSrcTall, 1>(C, CK_NB, src, np, r0, c0, lds);
+    } else {                                                             // rows 64 .. 127 are padding: staging and barriers only
+        gemm_tile_d<8, CkSrcTall, 0>(C, CK_NB, src, np, r0, c0, lds);
+    }
 }
 
 // block columns J0 .. J0 + nJ - 1 of Sigma (lower tiles in front of the padding) and of the mpad right-hand-side rows, by the
 // panels K0 .. K0 + np - 1 (single process: every panel in its own storage)
+// mrows: right-hand-side rows in front of the padding (m + 1; <= 0: treat all mpad rows as live)
 void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux, int64_t mpad, int K0, int np, int J0, int nJ,
-                          int64_t nvalid) {
+                          int64_t nvalid, int64_t mrows) {
     if (nJ <= 0 || np <= 0) return;
     const CkTileMap map = ck_tilemap_make(nvalid, J0, 1, nJ, (int)(mpad / 128));
     if (map.total <= 0) return;
-    k_tall_group_d<<<dim3((unsigned)map.total), dim3(512), 0, s>>>(sigptr_dev, aux, (long)mpad, K0, np, map);
+    const int thin_tm = mrows > 0 && mrows % 128 >= 1 && mrows % 128 <= 16 ? (int)(mrows / 128) : -1;
+    k_tall_group_d<<<dim3((unsigned)map.total), dim3(512), 0, s>>>(sigptr_dev, aux, (long)mpad, K0, np, map, thin_tm);
 }
 
 // Schur complement of the prediction sites, S = C_pp - V^T V (ck_verify_model): the solved right-hand-side rows
