@@ -77,3 +77,10 @@ print(f"{len(holes)} stretches > 20 us without a chip-filling launch, total {sum
 for s, e in sorted(holes, key=lambda h: -(h[1] - h[0]))[:10]:
     inside = sorted(set(n.split('<')[0][:24] for a, b, n, wg, _ in P if a < e and b > s and wg < 2048))
     print(f"   at {(s - t0) / 1e6:8.2f} ms: {(e - s) / 1e3:8.1f} us   running: {', '.join(inside)}")
+# optional third argument: list every dispatch of the last so-many ms of the pass (start, duration, workgroups, queue)
+if len(sys.argv) > 3:
+    tail_ms = float(sys.argv[3])
+    print(f"dispatches of the last {tail_ms} ms (and of the first {tail_ms / 2} ms):")
+    for s, e, n, wg, q in P:
+        if s >= t1 - tail_ms * 1e6 or s <= t0 + tail_ms * 0.5e6:
+            print(f"   {(s - t0) / 1e6:9.3f} ms  {(e - s) / 1e3:8.1f} us  {wg:6d} wg  q{q}  {n.split('<')[0][:28]}")
