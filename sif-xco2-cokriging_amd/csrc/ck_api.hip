@@ -973,6 +973,9 @@ static int64_t aux_rows(const ck_handle* h, int K) {
     return std::min(h->mpad, roundup(std::max<int64_t>(live, 1), CK_AUX_ALIGN));
 }
 
+// rows of the right-hand-side block in front of its padding, for the thin last tile row (0: treat every row as live)
+static int64_t aux_live(const ck_handle* h) { return h->loo_g0 < 0 && h->tall_thin ? h->m + 1 : 0; }
+
 static void aux_inner_on(ck_handle* h, int K, const double* P, hipStream_t st) {
     double* X = h->aux + (int64_t)K * h->mpad * CK_NB;
     const double* tail = P + (h->Npad - (int64_t)K * CK_NB) * CK_NB;
@@ -999,7 +1002,7 @@ static void aux_update_on(ck_handle* h, int K, const double* P, int Jlo, int Jhi
     timed = timed && h->time_gemm == 1;   // 2: only the Sigma updates are timed (one event list per sweep)
     (void)P;
     if (timed) gemm_timed_begin(h, st);
-    ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, rows, h->nend);
+    ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K, 1, Jlo, nJ, rows, h->nend, aux_live(h));
     if (timed) gemm_timed_end(h, st);
 }
 
@@ -1078,7 +1081,7 @@ extern "C" int ck_panel_apply_group(ck_handle* h, int K0, int np, int what, int 
         if (a <= b) {
             const bool timed = h->time_gemm == 1;
             if (timed) gemm_timed_begin(h);
-            ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, np, a, b - a + 1, aux_rows(h, K0 + np - 1), h->nend);
+            ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, np, a, b - a + 1, aux_rows(h, K0 + np - 1), h->nend, aux_live(h));
             if (timed) gemm_timed_end(h);
         }
     }
@@ -1241,7 +1244,7 @@ static int solve_sweep(ck_handle* h) {
             for (int g = 0; g < Gc; ++g) {
                 if (g > 0) {
                     gemm_timed_begin(h);
-                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend);
+                    ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend, aux_live(h));
                     gemm_timed_end(h);
                 }
                 aux_inner_on(h, K0 + g, h->sig[K0 + g], h->stream);
@@ -1249,7 +1252,7 @@ static int solve_sweep(ck_handle* h) {
             if (K0 + Gc < h->nK) {
                 gemm_timed_begin(h);
                 ck_launch_aux_group(h->stream, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc,
-                                    aux_rows(h, K0 + Gc - 1), h->nend);
+                                    aux_rows(h, K0 + Gc - 1), h->nend, aux_live(h));
                 gemm_timed_end(h);
             }
         }
@@ -1286,11 +1289,11 @@ static int fused_sweeps(ck_handle* h) {
         if (K0 + Gc < h->nK) syrk_update(h, F, K0, Gc, K0 + Gc, 1, h->nK - K0 - Gc);
         HIPCHK(hipStreamWaitEvent(M, h->ev_pan[ge], 0));
         for (int g = 0; g < Gc; ++g) {
-            if (g > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend);
+            if (g > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, g, K0 + g, 1, aux_rows(h, K0 + g - 1), h->nend, aux_live(h));
             aux_inner_on(h, K0 + g, h->sig[K0 + g], M);
         }
         if (K0 + Gc < h->nK)
-            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend);
+            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend, aux_live(h));
     }
     HIPCHK(hipEventRecord(h->ev1, F));               // end of the factorisation
     HIPCHK(hipEventRecord(h->ev2, M));               // end of the substitution
@@ -1342,11 +1345,11 @@ static int fused_sweeps_la(ck_handle* h) {
         if (g + 3 < ng) syrk_update(h, T, K0, Gc, first(g + 3), 1, h->nK - first(g + 3));   // B2(g)
         HIPCHK(hipStreamWaitEvent(M, h->ev_pan[g], 0));
         for (int q = 0; q < Gc; ++q) {
-            if (q > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, q, K0 + q, 1, aux_rows(h, K0 + q - 1), h->nend);
+            if (q > 0) ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, q, K0 + q, 1, aux_rows(h, K0 + q - 1), h->nend, aux_live(h));
             aux_inner_on(h, K0 + q, h->sig[K0 + q], M);
         }
         if (K0 + Gc < h->nK)
-            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend);
+            ck_launch_aux_group(M, h->aux, h->mpad, h->d_panelptr, K0, Gc, K0 + Gc, h->nK - K0 - Gc, aux_rows(h, K0 + Gc - 1), h->nend, aux_live(h));
     }
     HIPCHK(hipEventRecord(h->ev1, C));               // end of the factorisation's chain: the last panel is final
     HIPCHK(hipEventRecord(h->ev2, T));

@@ -105,7 +105,7 @@ void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux,
 void ck_launch_panel_coop_prof(hipStream_t s, double* P, int64_t nrows, double* tail, int64_t g0, long long* info,
                                unsigned* flags, unsigned seq, unsigned* err, long long* prof);
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int64_t mrows, int64_t nvalid);
+                         int nJ, int64_t mrows, int64_t nvalid, int64_t live_rows = 0);
 // S_J -= sum_p aux_p[rows of J..] aux_p[rows of block J]^T for the nJ block columns of the prediction sites' Schur
 // complement (ck_verify_model); aux: np block columns of mpad x CK_NB solved right-hand-side rows
 void ck_launch_schur_syrk(hipStream_t s, double* const* schur_dev, const double* aux, int64_t mpad, int np, int nJ,

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_syrk_group_d
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(double* __restrict__ aux, long mpad,
                                                         double* const* __restrict__ sigptr, int K0, int np, int J0,
-                                                        long mrows, long nvalid) {
+                                                        long mrows, long nvalid, int thin_tm) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     const int J = J0 + (int)blockIdx.y;
     const int tiles_n = CK_NB / 128;
@@ -605,7 +605,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 2) void k_aux_group_d(
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     if ((long)J * CK_NB + c0 >= nvalid) return;   // columns of the identity padding: the rows of L there are zero
     const CkSrcAux src{aux, mpad, sigptr, K0, J, r0, c0};
-    gemm_tile_d<WAVES>(aux + (long)J * mpad * CK_NB, CK_NB, src, np, r0, c0, lds);
+    double* C = aux + (long)J * mpad * CK_NB;
+    if (tm != thin_tm) {   // (thin_tm: see k_tall_group_d)
+        gemm_tile_d<WAVES>(C, CK_NB, src, np, r0, c0, lds);
+    } else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) {
+        gemm_tile_d<WAVES, CkSrcAux, 1>(C, CK_NB, src, np, r0, c0, lds);
+    } else {
+        gemm_tile_d<WAVES, CkSrcAux, 0>(C, CK_NB, src, np, r0, c0, lds);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -718,10 +725,12 @@ void ck_launch_syrk_group(hipStream_t s, double* const* sigptr_dev, double* cons
 // mrows (a multiple of 128, <= mpad): only the first mrows right-hand-side rows are updated -- the leave-one-out
 // sweep knows that the others are still zero in these columns
 void ck_launch_aux_group(hipStream_t s, double* aux, int64_t mpad, double* const* sigptr_dev, int K0, int np, int J0,
-                         int nJ, int64_t mrows, int64_t nvalid) {
+                         int nJ, int64_t mrows, int64_t nvalid, int64_t live_rows) {
     if (nJ <= 0 || np <= 0 || mrows <= 0) return;
     const dim3 grid((unsigned)((mrows / 128) * (CK_NB / 128)), (unsigned)nJ);
-    k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows, nvalid);
+    // live_rows: rows in front of the padding (m + 1; 0: all) -- a last tile row with at most 16 of them computes their block only
+    const int thin_tm = live_rows > 0 && live_rows % 128 >= 1 && live_rows % 128 <= 16 ? (int)(live_rows / 128) : -1;
+    k_aux_group_d<8><<<grid, dim3(512), 0, s>>>(aux, mpad, sigptr_dev, K0, np, J0, mrows, nvalid, thin_tm);
 }
 
 // plain (optionally batched over blockIdx.y) form
