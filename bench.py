@@ -508,7 +508,8 @@ def main():
                     "whole_step": {"flops": N ** 3 / 3 + N ** 2 * m, "ms": ms_per_step,
                                    "frac_of_mfma_peak": (N ** 3 / 3 + N ** 2 * m) / (ms_per_step / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS},
                     "measured_on": "the timed steps themselves, HIP events around every launch of the kernel on the stream it is launched "
-                                   "on: achieved = the algorithmic flops of its launches of a step (every 128 x 128 tile's 2 x 128 x 128 x K) "
+                                   "on: achieved = the algorithmic flops of its launches of a step (2 K per lower-triangle entry and per entry of the m + 1 "
+                                   "right-hand-side rows; padding and the upper halves of diagonal tiles are executed but not counted) "
                                    "over union_launch_ms, the time during which the kernel is running at all -- its launches run on two "
                                    "streams and overlap each other (look-ahead), so sum_launch_ms exceeds it (avg_launch_ms = sum / "
                                    "launches is what rocprofv3's kernel stats average: profiles/r04_bench_n20k_kernel_stats.csv).  "

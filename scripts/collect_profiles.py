@@ -26,12 +26,14 @@ def cp(src, dst):
 cp(f"{G}/prof_{tag}_bench.txt", f"{tag}_bench_n20k_rocprof_summary.txt")
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     cp(f"{G}/prof_{tag}/{sub}_per_kernel_mean.csv", f"{tag}_{sub}_per_kernel_mean.csv")
+# (gpurun merges every call's output into the same directories: take the NEWEST file, not the first)
+newest = lambda files: max(files, key=os.path.getmtime)
 st = glob.glob(f"{G}/prof_{tag}/trace/**/*kernel_stats.csv", recursive=True)
 if st:
-    cp(st[0], f"{tag}_bench_n20k_kernel_stats.csv")
+    cp(newest(st), f"{tag}_bench_n20k_kernel_stats.csv")
 so = glob.glob(f"{G}/prof_{tag}/trace_sequential/**/*kernel_stats.csv", recursive=True)
 if so:
-    cp(so[0], f"{tag}_trace_sequential_kernel_stats.csv")   # --sweeps sequential: round 3's two kernels, each with the chip to itself
+    cp(newest(so), f"{tag}_trace_sequential_kernel_stats.csv")   # --sweeps sequential: round 3's two kernels, each with the chip to itself
 cp(f"{G}/prof_{tag}_bench_line.json", f"{tag}_bench_n20k.json")
 cp(f"{G}/prof_{tag}_bench_config1.json", f"{tag}_bench_config1_n5k.json")
 cp(f"{G}/prof_{tag}_bench_n50k.json", f"{tag}_bench_n50k_1gpu.json")
@@ -49,7 +51,7 @@ cp(f"{G}/prof_{tag}_bench_2rank_gloo.json", f"{tag}_bench_2rank_gloo_one_gpu.jso
 for name, out in ((f"prof_vario_{tag}", f"{tag}_variogram_1M_kernel_stats.csv"), (f"prof_local_{tag}", f"{tag}_local_400km_kernel_stats.csv")):
     f = glob.glob(f"{G}/{name}/**/*kernel_stats.csv", recursive=True)
     if f:
-        cp(f[0], out)
+        cp(newest(f), out)
 
 # ---- traffic of k_tall_group_d -------------------------------------------------------------------
 fe, wr = f"{P}/{tag}_pmc_fetch_per_kernel_mean.csv", f"{P}/{tag}_pmc_write_per_kernel_mean.csv"

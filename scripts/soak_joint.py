@@ -26,7 +26,7 @@ for trial in range(ntrial):
     pv[10] *= rng.uniform(0.2, 1.0)
     coords = [pb["coords"][0][:n0], pb["coords"][1][:n1]]
     values = [pb["values"][0][:n0], pb["values"][1][:n1]]
-    m = int(rng.choice([1, 5, 255, 256, 300, 700]))
+    m = int(rng.choice([1, 5, 127, 128, 140, 255, 256, 300, 700]))
     pc = pb["pcoords"][rng.permutation(len(pb["pcoords"]))[:m]]
     h = native.Handle(0)
     opts = {"site_order": int(rng.integers(0, 2)), "panel_group": int(rng.integers(0, 5)),
@@ -51,7 +51,8 @@ for trial in range(ntrial):
         # group plans with a short first group / small groups at the tail)
         fo = {"fused_prio": int(rng.integers(0, 3)), "fused_group": int(rng.integers(0, 5)), "fused_la": int(rng.integers(-1, 2)),
               "tall_sweep": int(rng.random() < 0.75), "group_first": int(rng.integers(0, 3)), "group_tail": int(rng.integers(0, 3)),
-              "group_tail_panels": int(rng.integers(0, 6))}
+              "group_tail_panels": int(rng.integers(0, 6)), "tall_split": int(rng.integers(0, 3)),
+              "tall_split_rows": int(rng.choice([0, 1024, 12288])), "tall_thin": int(rng.random() < 0.8)}
         for k, v in fo.items():
             h.set_option(k, v)
         opts.update(fo)

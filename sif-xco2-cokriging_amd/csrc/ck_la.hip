@@ -640,17 +640,30 @@ struct CkSrcTall {
     }
 };
 
-// thin_tm: the right-hand-side tile row with at most 16 rows in front of the padding (-1: none) -- gemm_tile_d's NI
+// thin_tm: the right-hand-side tile row with at most 16 rows in front of the padding (-1: none) -- gemm_tile_d's NI.  Its tiles are
+// NOT part of the map (which then holds one right-hand-side tile row fewer): they are the last workgroups of the grid, dealt to the
+// XCDs round-robin.  In launch order they finished in a third of a tile's time and put every later tile of their slot out of step
+// with the tiles it shares operand rows with: FETCH_SIZE per launch rose by 45 % (21.6 -> 31.4 GB for the largest launch).
 __global__ __launch_bounds__(512, 4) void k_tall_group_d(double* const* __restrict__ sigptr, double* __restrict__ aux, long mpad,
                                                           int K0, int np, const CkTileMap map, int thin_tm) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 256 * 128];
     int u, tm, tn;
-    const bool ax = ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
+    bool ax;
+    const bool thin = (long long)blockIdx.x >= map.total;   // block-uniform
+    if (!thin) {
+        ax = ck_tilemap_get(map, xcd_remap(blockIdx.x, (int)map.total), u, tm, tn);
+    } else {
+        const int q = (int)((long long)blockIdx.x - map.total);   // tile columns 0 .. 3 of the full block columns, then the short one's
+        u = q >> 2 < map.nfull ? q >> 2 : map.nfull;
+        tn = q - 4 * u;
+        tm = thin_tm;
+        ax = true;
+    }
     const int J = map.J0 + u * map.Jstep;
     const long r0 = (long)tm * 128, c0 = (long)tn * 128;
     const CkSrcTall src{sigptr, aux, mpad, K0, J, r0, c0, ax};
     double* C = ax ? aux + (long)J * mpad * CK_NB : sigptr[J];
-    if (!(ax && tm == thin_tm)) {
+    if (!thin) {
         gemm_tile_d<8>(C, CK_NB, src, np, r0, c0, lds);
     } else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) {   // the waves of rows 0 .. 63: their first 16-row block
         gemm_tile_d<8, CkSrcTall, 1>(C, CK_NB, src, np, r0, c0, lds);
@@ -665,10 +678,12 @@ __global__ __launch_bounds__(512, 4) void k_tall_group_d(double* const* __restri
 void ck_launch_tall_group(hipStream_t s, double* const* sigptr_dev, double* aux, int64_t mpad, int K0, int np, int J0, int nJ,
                           int64_t nvalid, int64_t mrows) {
     if (nJ <= 0 || np <= 0) return;
-    const CkTileMap map = ck_tilemap_make(nvalid, J0, 1, nJ, (int)(mpad / 128));
+    const int axr = (int)(mpad / 128);
+    const int thin_tm = mrows > 0 && mrows % 128 >= 1 && mrows % 128 <= 16 && mrows / 128 == axr - 1 ? axr - 1 : -1;
+    const CkTileMap map = ck_tilemap_make(nvalid, J0, 1, nJ, thin_tm >= 0 ? axr - 1 : axr);
     if (map.total <= 0) return;
-    const int thin_tm = mrows > 0 && mrows % 128 >= 1 && mrows % 128 <= 16 ? (int)(mrows / 128) : -1;
-    k_tall_group_d<<<dim3((unsigned)map.total), dim3(512), 0, s>>>(sigptr_dev, aux, (long)mpad, K0, np, map, thin_tm);
+    const long long nthin = thin_tm >= 0 ? 4LL * map.nfull + map.tv_last : 0;
+    k_tall_group_d<<<dim3((unsigned)(map.total + nthin)), dim3(512), 0, s>>>(sigptr_dev, aux, (long)mpad, K0, np, map, thin_tm);
 }
 
 // Schur complement of the prediction sites, S = C_pp - V^T V (ck_verify_model): the solved right-hand-side rows
