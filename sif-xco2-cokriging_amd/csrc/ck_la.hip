@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void lt_diag_update(double* __restrict__ S, long ld, 
 // potrf64_body the transposed factor lives in the block-upper part (Lt[c][i], c <= i) and the inverse in the
 // block-lower part (Wi[r][c], c <= r); the 16 x 16 diagonal blocks of Lt are dead once step A of the inverse has
 // read them, which is when the diagonal blocks of Wi are written (same wave, program order).
-__global__ __launch_bounds__(256) void k_lt_potrf64(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
+__global__ __launch_bounds__(256, 3) void k_lt_potrf64(const CkLocalSys* __restrict__ sys, double* __restrict__ slab, int g0,
                                                      int i, long long* info) {
     __shared__ __attribute__((aligned(16))) double M[64][66];
     const CkLocalSys q = sys[blockIdx.x];
