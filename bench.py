@@ -256,7 +256,10 @@ def main():
         pg = os.environ.get("CK_PANEL_GROUP", "auto")
         runner = distributed.DistributedJoint(h, rank, world, dist_module=dist, device=torch.device("cuda", local_rank),
                                               exchange=os.environ.get("CK_PANEL_EXCHANGE", "auto"),
-                                              panel_group=pg if pg == "auto" else int(pg))
+                                              panel_group=pg if pg == "auto" else int(pg),
+                                              # CK_CHAIN_STREAM=1 (with CK_PANEL_GROUP=1): the next panel's column update, step and
+                                              # exchange on a second stream under the bulk update -- opt-in until a multi-GPU box has run it
+                                              chain_stream=os.environ.get("CK_CHAIN_STREAM", "0") == "1")
         runner.prepare(m_total=m)
         h.set_option("time_gemm", 2)   # HIP events around this rank's Sigma trailing-update launches
         cand = os.environ.get("CK_PANEL_EXCHANGE_CANDIDATES")

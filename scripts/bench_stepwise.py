@@ -39,9 +39,10 @@ for r in range(reps + 1):
     if r:
         print(f"N={2 * n} single process (ck_factor_predict, after ck_assemble_joint): {dt:8.2f} ms", flush=True)
 h.close()
-for G in (1, 3, 4):
+for G in (1, "1 + chain stream", 3, 4):
     h = handle()
-    run = DistributedJoint(h, 0, 1, device=torch.device("cuda", 0), panel_group=G).prepare(len(pc))
+    cs = isinstance(G, str)
+    run = DistributedJoint(h, 0, 1, device=torch.device("cuda", 0), panel_group=1 if cs else G, chain_stream=cs).prepare(len(pc))
     for r in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

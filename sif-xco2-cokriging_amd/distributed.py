@@ -101,7 +101,7 @@ class DistributedJoint:
       storage for G = 3 and autotune() times one pass of either schedule and keeps the faster."""
 
     def __init__(self, handle, rank: int, world: int, dist_module=None, device=None, group=None, lookahead=True,
-                 exchange: str = "broadcast", panel_group=1, rehearse_collectives: bool = False):
+                 exchange: str = "broadcast", panel_group=1, rehearse_collectives: bool = False, chain_stream: bool = False):
         self.h, self.rank, self.world = handle, int(rank), int(world)
         self.dist, self.device, self.group = dist_module, device, group
         self.lookahead = bool(lookahead)
@@ -130,6 +130,11 @@ class DistributedJoint:
         self._caller_order = False   # set once a not-positive-definite Sigma has been re-swept in the caller's order
         self._resident = False       # the factor of the last predict() is still in the panels
         self._xstream = None
+        # chain_stream (per-panel schedule, GPU only; off by default until a multi-GPU box has run it): the next panel's column
+        # update, panel step and exchange go to a second, high-priority stream and run UNDER the current panel's bulk update
+        # instead of in front of it (_sweep_chain_stream) -- the look-ahead of the single-process tall sweep in the step-wise form
+        self.chain_stream = bool(chain_stream)
+        self._cstream = None
 
     # -- setup ------------------------------------------------------------------------------------
     def shard(self, m_total: int):
@@ -395,6 +400,55 @@ class DistributedJoint:
                 work.wait()
             self._steps.append((t0, t1, t2, mk()))
 
+    def _sweep_chain_stream(self, nK):
+        """_sweep_lookahead with the chain on its own stream.  Per panel K, stream M (the handle's): the bulk update by panel K
+        (block columns beyond K + 1, right-hand sides); stream C (high priority): block column K + 1 by panel K, its panel step,
+        its exchange.  C starts behind an event on M that stands behind M's wait for panel K AND behind the bulk update of panel
+        K - 1 -- which wrote block column K + 1 and was the last reader of the receive slot the exchange of panel K + 1 writes --;
+        M waits for C's end (and the exchange) before it touches panel K + 1.  Same kernels, same order per block column: same
+        bits as the other schedules."""
+        import torch
+        h, mk, world, me = self.h, self._marks.mark, self.world, self.rank
+        M = torch.cuda.current_stream(self.device)
+        if self._cstream is None:
+            self._cstream = torch.cuda.Stream(device=self.device, priority=-1)
+        C = self._cstream
+        t0 = mk()
+        if me == 0:
+            h.panel_factor(0)
+        t1 = mk()
+        if self._comm:
+            self._exchange(0, 0)
+        self._steps.append((t0, t1, t1, mk()))
+        for K in range(nK):
+            nxt, work, done = K + 1, None, None
+            t0 = mk()
+            if nxt < nK:
+                ready = torch.cuda.Event()
+                ready.record(M)
+                C.wait_event(ready)
+                with torch.cuda.stream(C):
+                    h.set_stream(C.cuda_stream)
+                    try:
+                        if nxt % world == me:
+                            h.panel_apply_sigma(K, nxt, nxt)
+                            h.panel_factor(nxt)
+                        if self._comm:
+                            work = self._exchange(nxt, nxt % world, async_op=True)
+                        done = torch.cuda.Event()
+                        done.record(C)
+                    finally:
+                        h.set_stream(M.cuda_stream)
+            t1 = mk()
+            h.panel_apply_sigma(K, nxt + 1, nK - 1)
+            h.panel_apply(K, native.APPLY_AUX)
+            t2 = mk()
+            if done is not None:
+                M.wait_event(done)
+            if work is not None:
+                work.wait()
+            self._steps.append((t0, t1, t2, mk()))
+
     def _sweep_grouped(self, nK, G):
         """Trailing updates for G panels at once (contraction dimension 512 G: a G-th of the read-modify-write traffic
         of the per-panel schedule), with the look-ahead kept: while the group K0 .. K0 + G - 1 is resident on every
@@ -498,6 +552,8 @@ class DistributedJoint:
             self._sweep_solve_only(nK)
         elif self.G > 1:
             self._sweep_grouped(nK, self.G)
+        elif self.chain_stream and self.lookahead and self._marks.cuda:
+            self._sweep_chain_stream(nK)
         elif self._comm and self.lookahead:
             self._sweep_lookahead(nK)
         else:

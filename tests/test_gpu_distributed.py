@@ -102,7 +102,9 @@ def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast", gro
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         dm = _GlooViaHost(dist) if via_host else dist   # raw gloo on device tensors: really asynchronous broadcasts
-        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange, panel_group=group).prepare(len(g["pcoords_A"]))
+        chain = group == "chain"    # the per-panel schedule with the chain on its own high-priority stream (opt-in)
+        r = DistributedJoint(h, rank, world, dist_module=dm, device=dev, exchange=exchange, panel_group=1 if chain else group,
+                             chain_stream=chain).prepare(len(g["pcoords_A"]))
         if exchange == "auto":
             info = r.calibrate(reps=1, candidates=("broadcast", "sag", "p2p"))
             assert r.exchange in ("broadcast", "sag", "p2p") and info["calibration_ms"]["broadcast"] is not None, info
@@ -117,7 +119,8 @@ def _worker(rank, world, port, q, via_host, big=False, exchange="broadcast", gro
 
 @pytest.mark.parametrize("via_host,big,world,exchange,group", [
     (True, False, 2, "broadcast", 1), (False, False, 2, "broadcast", 1), (False, True, 2, "broadcast", 1),
-    (True, True, 3, "p2p", 1), (False, True, 2, "broadcast", 3), (True, True, 3, "p2p", 2), (False, True, 3, "auto", "auto")])
+    (True, True, 3, "p2p", 1), (False, True, 2, "broadcast", 3), (True, True, 3, "p2p", 2), (False, True, 3, "auto", "auto"),
+    (False, True, 2, "broadcast", "chain"), (True, True, 3, "p2p", "chain"), (False, True, 3, "sag", "chain")])
 def test_two_ranks_one_gpu_matches_oracle(via_host, big, world, exchange, group):
     """(p2p: three ranks, every panel scattered by its owner and passed on point to point; group 2 / 3: trailing updates
     for that many panels at once with the next group's panel steps in between; auto: exchange and schedule chosen by
@@ -182,6 +185,14 @@ def test_world1_driver_with_arena_matches_direct():
     p2, e2 = h2.predict(1, g["pcoords_R"])
     assert np.array_equal(p1, p2) and np.array_equal(e1, e2)
     assert np.max(np.abs(p1 - g["pred_R_1"])) / np.max(np.abs(g["pred_R_1"])) < 1e-9
+    # the same with the next panel's column update and panel step on a second stream under the bulk update (chain_stream)
+    h3 = mk()
+    r3 = DistributedJoint(h3, 0, 1, device=torch.device("cuda", 0), chain_stream=True).prepare(len(g["pcoords_R"]))
+    p3, e3 = r3.predict(1, g["pcoords_R"])
+    assert np.array_equal(p3, p2) and np.array_equal(e3, e2)
+    p4, e4 = r3.predict(0, g["pcoords_R"])
+    p5, e5 = h2.predict(0, g["pcoords_R"])
+    assert np.array_equal(p4, p5) and np.array_equal(e4, e5)
 
 
 def test_step_wise_driver_reports_the_failing_minor_in_the_callers_order():
@@ -435,10 +446,13 @@ def _worker_rccl_single(q, port):
         single_ms = (time.perf_counter() - t0) / 3 * 1e3
         href.close()
         res = {"single_process_ms": single_ms}
-        for exchange, group in (("broadcast", 1), ("sag", 1), ("p2p", 1), ("auto", 3), ("sag", 3)):
+        # ("chain": the per-panel schedule with the chain and its exchange on a second, high-priority stream -- RCCL works issued
+        # from that stream, waited for on the handle's)
+        for exchange, group in (("broadcast", 1), ("sag", 1), ("p2p", 1), ("auto", 3), ("sag", 3), ("broadcast", "chain"), ("sag", "chain")):
             h = mk()
-            r = DistributedJoint(h, 0, 1, dist_module=dist, device=dev, exchange=exchange, panel_group=group,
-                                 rehearse_collectives=True).prepare(len(pc))
+            chain = group == "chain"
+            r = DistributedJoint(h, 0, 1, dist_module=dist, device=dev, exchange=exchange, panel_group=1 if chain else group,
+                                 rehearse_collectives=True, chain_stream=chain).prepare(len(pc))
             if exchange == "auto":
                 info = r.calibrate(reps=1, candidates=("broadcast", "sag", "p2p"))   # _reduce_max: device all_reduce; barrier
                 assert all(v is not None for v in info["calibration_ms"].values()), info
