@@ -421,7 +421,7 @@ class DistributedJoint:
             self._exchange(0, 0)
         self._steps.append((t0, t1, t1, mk()))
         for K in range(nK):
-            nxt, work, done = K + 1, None, None
+            nxt, work, done, solved = K + 1, None, None, None
             t0 = mk()
             if nxt < nK:
                 ready = torch.cuda.Event()
@@ -430,6 +430,11 @@ class DistributedJoint:
                 with torch.cuda.stream(C):
                     h.set_stream(C.cuda_stream)
                     try:
+                        # the right-hand-side rows' walk through panel K (140 small workgroups) rides on C as well: it only
+                        # needs panel K and what the bulk update of panel K - 1 left in block column K (behind `ready`)
+                        h.panel_aux_solve(K)
+                        solved = torch.cuda.Event()
+                        solved.record(C)
                         if nxt % world == me:
                             h.panel_apply_sigma(K, nxt, nxt)
                             h.panel_factor(nxt)
@@ -441,7 +446,11 @@ class DistributedJoint:
                         h.set_stream(M.cuda_stream)
             t1 = mk()
             h.panel_apply_sigma(K, nxt + 1, nK - 1)
-            h.panel_apply(K, native.APPLY_AUX)
+            if solved is not None:
+                M.wait_event(solved)
+                h.panel_apply_group(K, 1, native.APPLY_AUX, nxt, nK - 1)
+            else:
+                h.panel_apply(K, native.APPLY_AUX)
             t2 = mk()
             if done is not None:
                 M.wait_event(done)
