@@ -505,6 +505,11 @@ def main():
                     "launches_per_step": nl, "avg_launch_ms": sum_ms / max(nl, 1), "sum_launch_ms": sum_ms,
                     "union_launch_ms": union_s * 1e3, "span_ms": span_s * 1e3,
                     "frac_over_sweep_span": fl_all / span_s / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                    # for the record: the same flops over the SUM of the launch durations (= launches x avg_launch_ms, what a
+                    # per-kernel average from rocprofv3 multiplies out to).  The launches of the two streams overlap each other,
+                    # so a launch's duration includes the time it shares the chip with another launch of the same kernel: this
+                    # figure counts that time twice and is a lower bound, not the kernel's rate
+                    "frac_over_sum_of_launch_durations": fl_all / (sum_ms / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                     "algorithmic_flops_per_step": fl_all,
                     # everything a step computes (N^3/3 + N^2 m: the kernel's launches + the panel steps) over the whole step's
                     # wall time (assembly, sweep, reductions, host): the figure VERDICT r03 quotes as "whole step"
