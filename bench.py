@@ -300,12 +300,14 @@ def main():
     tim_fused = tim
     seq_ms = None
     result_check = None
+    resident = None
     if world == 1 and args.sweeps == "sequential":
         seq_ms = ms_per_step
     elif world == 1:
         # stage measurements: sequential passes of the same workload, outside the timed region -- and the check that the
         # product schedule of the timed steps (one sweep over the tall matrix, two streams) gives the sequence's BITS
         n_seq = max(1, min(args.steps, 3))
+        h.set_option("solve_la", 0)     # the reference passes: ck_predict's sweep one launch after the other (chip to itself)
         step_sequential()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -315,6 +317,17 @@ def main():
             tim.append(h.timings())
         torch.cuda.synchronize()
         seq_ms = (time.perf_counter() - t0) / n_seq * 1e3
+        # one more prediction on the resident factor with the product's defaults (Predictor.__call__ for the second field, a new
+        # grid): ck_predict with the chain of the next panel group under the bulk of the current one (option solve_la)
+        h.set_option("solve_la", -1)
+        h.predict(0, pb["pcoords"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pred_r, err_r = h.predict(0, pb["pcoords"])
+        resident = {"ms": (time.perf_counter() - t0) * 1e3, "sweep_ms": h.timings()["solve_ms"],
+                    "equals_sequential_pass": bool(np.array_equal(pred_r, pred_s) and np.array_equal(err_r, err_s)),
+                    "what": "ck_predict on the resident factor, product defaults (host arrays -> host results): K2, the forward sweep with "
+                            "look-ahead, reduce"}
         result_check = {"timed_steps_equal_sequential_passes": bool(np.array_equal(pred, pred_s) and np.array_equal(err, err_s)),
                         "max_abs_diff": float(max(np.max(np.abs(pred - pred_s)), np.max(np.abs(err - err_s)))),
                         "what": "(pred, pred_err) of the last timed step (ck_factor_predict, the product schedule) against the last "
@@ -574,6 +587,7 @@ def main():
                 "cov_assembly_frac_of_fp64_valu_peak": 14.0 * (N * (N + 1) / 2) / (k1_ms / 1e3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                 # factor reused: grid-points/s of one more ck_predict on the resident L (K2 + K4 + reduce)
                 "amortised_grid_points_per_s": m / ((tl["assemble_aux_ms"] + tl["solve_ms"] + tl["reduce_ms"]) / 1e3),
+                "resident_factor_predict": resident,
             }
             if pcie is not None:
                 out["pcie_inclusive"] = pcie
@@ -582,7 +596,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, m)
         print(json.dumps(out), flush=True)
-        if result_check is not None and not result_check["timed_steps_equal_sequential_passes"]:
+        if (result_check is not None and not result_check["timed_steps_equal_sequential_passes"]) or \
+                (resident is not None and not resident["equals_sequential_pass"]):
             raise SystemExit("bench.py: the timed steps' results differ from the sequential passes' (result_check)")
 
 

@@ -364,6 +364,9 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * steps of panels behind the first group with at least that many rows run as the cooperative launch on the 512 x 512 head only plus
  * ONE launch of k_panel_rows_all for every other row of the panel and of the right-hand sides -- no workgroup holds a slot while it
  * waits for the head (same bits; N = 40 000: 0.5 % faster);
+ * "solve_la" (-1 automatic = from 40 panels, 0, 1): ck_predict's sweep on a resident factor with the chain of the next panel group (the
+ * one-column in-group updates, which fill 55 % of the chip, and the rows' walk through each panel) on the high-priority stream UNDER the
+ * bulk update of the current group instead of in front of it (N = 40 000: 210 -> 205 ms; same bits);
  * "tall_thin" (0/1, default 1): a last right-hand-side tile row with at most 16 rows in front of the padding (m + 1 = 8 834: two rows)
  * computes those rows' 16-row block only (same bits, 0.35 % at N = 40 000);
  * "assemble_queue" (-1 automatic, 0 off, else the number of workgroups): the table-path assembly kernels as a resident set of

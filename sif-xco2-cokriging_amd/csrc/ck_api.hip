@@ -181,6 +181,7 @@ struct ck_handle {
                                       // every other row (Sigma's and the right-hand sides') through k_panel_rows_all (0: never, 1: every
                                       // panel, 2: panels behind the first group with at least tall_split_rows rows)
     int tall_split_rows = 24 * CK_NB; // tall_split 2: shorter panels keep the one cooperative launch
+    int solve_la = -1;                // ck_predict's sweep with the chain of the next group under the bulk of the current one (-1: from 40 panels)
     int tall_thin = 1;                // tall sweep: a last right-hand-side tile row with <= 16 rows in front of the padding computes those only
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
@@ -1217,8 +1218,58 @@ static int factor_sweep(ck_handle* h) {
     return 0;
 }
 
+// The same sweep with the look-ahead of tall_sweeps (round 4; ck_predict on a resident factor -- the second field of a
+// Predictor, the sites of a new grid): stream C (high priority) carries the chain of group g -- the one-column in-group updates
+// (280 tiles: they fill 55 % of the chip) and the rows' walk through each panel -- and A(g), the update of the NEXT group's block
+// columns; stream T carries B1(g) / B2(g), the update of everything beyond.  The chain of group g + 1 runs under the bulk of group g
+// instead of in front of it.  Same launches on the same operands in the same order per block column: same bits.
+static int solve_sweep_la(ck_handle* h) {
+    if (ensure_events(h)) return -1;
+    if (!h->side_lo) HIPCHK(hipStreamCreateWithFlags(&h->side_lo, hipStreamNonBlocking));
+    hipStream_t C = h->side, T = h->side_lo, M = h->stream;
+    const std::vector<int> gs = group_plan(h, eff_group(h));
+    const int ng = (int)gs.size() - 1;
+    auto first = [&](int g) { return gs[(size_t)g]; };
+    auto count = [&](int g) { return gs[(size_t)g + 1] - gs[(size_t)g]; };
+    auto update = [&](hipStream_t st, int K0, int np, int J0, int nJ) {
+        if (nJ <= 0) return;
+        gemm_timed_begin(h, st);
+        ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K0, np, J0, nJ, aux_rows(h, K0 + np - 1), h->nend, aux_live(h));
+        gemm_timed_end(h, st);
+    };
+    HIPCHK(hipEventRecord(h->ev0, M));   // (ev0 / ev1 are free between ck_aux_begin and ck_aux_finish)
+    HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
+    HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
+    for (int g = 0; g < ng; ++g) {
+        const int K0 = first(g), Gc = count(g);
+        for (int q = 0; q < Gc; ++q) {
+            if (q > 0) update(C, K0, q, K0 + q, 1);
+            aux_inner_on(h, K0 + q, h->sig[K0 + q], C);
+        }
+        HIPCHK(hipEventRecord(h->ev_pan[g], C));   // group g's right-hand-side block columns are final
+        if (g + 1 < ng) {
+            if (g >= 1) HIPCHK(hipStreamWaitEvent(C, h->ev_col[g - 1], 0));   // B1(g - 1) wrote the same block columns
+            update(C, K0, Gc, first(g + 1), count(g + 1));                    // A(g)
+        }
+        HIPCHK(hipStreamWaitEvent(T, h->ev_pan[g], 0));
+        if (g + 2 < ng) {
+            update(T, K0, Gc, first(g + 2), count(g + 2));                    // B1(g)
+            HIPCHK(hipEventRecord(h->ev_col[g], T));
+        }
+        if (g + 3 < ng) update(T, K0, Gc, first(g + 3), h->nK - first(g + 3));   // B2(g)
+    }
+    HIPCHK(hipEventRecord(h->ev1, C));
+    HIPCHK(hipEventRecord(h->ev_col[(size_t)h->nK], T));   // (ensure_events: nK + 1 entries, the groups use at most nK)
+    HIPCHK(hipStreamWaitEvent(M, h->ev1, 0));
+    HIPCHK(hipStreamWaitEvent(M, h->ev_col[(size_t)h->nK], 0));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // forward sweep of the right-hand-side rows through the factor (the L panels are final)
 static int solve_sweep(ck_handle* h) {
+    const bool la = h->solve_la >= 0 ? h->solve_la != 0 : h->nK >= 40;
+    if (la && h->world == 1 && h->loo_g0 < 0 && (h->panel_fused & 2) && eff_group(h) > 1 && h->side) return solve_sweep_la(h);
     if (h->lookahead > 0) {
         if (ensure_events(h)) return -1;
         hipStream_t M = h->stream, S = h->side;
@@ -2886,6 +2937,11 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "tall_split")) {
         if (value < 0 || value > 2) return fail("tall_split must be 0, 1 or 2");
         h->tall_split = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "solve_la")) {
+        if (value < -1 || value > 1) return fail("solve_la must be -1, 0 or 1");
+        h->solve_la = (int)value;
         return 0;
     }
     if (!strcmp(name, "tall_thin")) {

@@ -637,6 +637,17 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     assert t["syrk_launches"] == launches, (t["syrk_launches"], launches)
     again = h2.predict(0, pc)                   # on the factor the tall sweep left resident
     assert np.array_equal(again[0], h.predict(0, pc)[0])
+    if group != 1:
+        # ck_predict's sweep with the chain of the next group under the bulk of the current one (option solve_la; automatic
+        # from 40 panels) against the launches one after the other: same bits, for both processes
+        h2.set_option("panel_group", group if group else 3)     # (11 panels: the automatic group size is one -- no look-ahead)
+        for la in (1, 0):
+            h2.set_option("solve_la", la)
+            for i in (1, 0):
+                a, b = h2.predict(i, pc), h.predict(i, pc)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (la, i)
+        h2.set_option("solve_la", -1)
+        h2.set_option("panel_group", 0)
     h3, _ = _assembled(native, params, coords, values, HAV)
     h3.set_option("tall_sweep", 0)              # round 3's two overlapped sweeps: still the same bits
     h3.set_option("fused_group", group)
