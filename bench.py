@@ -248,6 +248,7 @@ def main():
             return h.predict(0, pb["pcoords"])
         if args.sweeps == "sequential":
             step = step_sequential
+            h.set_option("solve_la", 0)   # "sequential" means it: every launch of either sweep with the chip to itself
     else:
         from sif_xco2_cokriging_amd import distributed
         # CK_PANEL_EXCHANGE = broadcast | sag | p2p | auto (default: one mid-size panel through each at warm-up, the
