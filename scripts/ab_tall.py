@@ -34,7 +34,7 @@ variants = [("plain", {}), ("two", {"tall_sweep": 0}), ("tall", {"tall_sweep": 1
             ("tallG5F3", {"tall_sweep": 1, "fused_group": 5, "group_first": 3}), ("tallG6F2", {"tall_sweep": 1, "fused_group": 6, "group_first": 2}),
             ("tallG6F3", {"tall_sweep": 1, "fused_group": 6, "group_first": 3}), ("tallG3F2", {"tall_sweep": 1, "fused_group": 3, "group_first": 2}),
             ("tallG4F2T", {"tall_sweep": 1, "fused_group": 4, "group_first": 2, "group_tail": 2, "group_tail_panels": 12}),
-            ("tallS0", {"tall_split": 0}), ("tallThick", {"tall_thin": 0}), ("tallS1", {"tall_split": 1}), ("tallS2R8", {"tall_split": 2, "tall_split_rows": 8 * 512}),
+            ("tallB2off", {"tall_b2_stream": 0}), ("tallS0", {"tall_split": 0}), ("tallThick", {"tall_thin": 0}), ("tallS1", {"tall_split": 1}), ("tallS2R8", {"tall_split": 2, "tall_split_rows": 8 * 512}),
             ("tallS2R16", {"tall_split": 2, "tall_split_rows": 16 * 512}), ("tallS2R32", {"tall_split": 2, "tall_split_rows": 32 * 512}),
             ("tallG2F1", {"tall_sweep": 1, "fused_group": 2, "group_first": 1}), ("tallG3F1", {"tall_sweep": 1, "fused_group": 3, "group_first": 1}),
             ("tallG3F2", {"tall_sweep": 1, "fused_group": 3, "group_first": 2}),
@@ -56,6 +56,7 @@ for it in range(reps):
             h.set_option(k_, 0)
         h.set_option("tall_split", 2)
         h.set_option("tall_thin", 1)
+        h.set_option("tall_b2_stream", 1)
         h.set_option("tall_split_rows", 24 * 512)
         for k_, v_ in opts.items():
             h.set_option(k_, v_)

@@ -182,6 +182,8 @@ struct ck_handle {
                                       // panel, 2: panels behind the first group with at least tall_split_rows rows)
     int tall_split_rows = 24 * CK_NB; // tall_split 2: shorter panels keep the one cooperative launch
     int solve_la = -1;                // ck_predict's sweep with the chain of the next group under the bulk of the current one (-1: from 40 panels)
+    int tall_b2_stream = 1;           // tall sweep: B2(g) on the handle's own stream beside B1(g)
+    std::vector<hipEvent_t> ev_b2;
     int tall_thin = 1;                // tall sweep: a last right-hand-side tile row with <= 16 rows in front of the padding computes those only
     int fused_la = -1;                // ck_factor_predict: look-ahead inside the factorisation (fused_sweeps_la); -1: from 40 panels
                                       // (N = 40 000: 522.3 -> 518.1 ms, three interleaved repetitions; N = 10 000: no difference)
@@ -321,6 +323,7 @@ extern "C" int ck_destroy(ck_handle* h) {
     (void)hipEventDestroy(h->ev2);
     (void)hipEventDestroy(h->ev3);
     if (h->mv_buf) (void)hipFree(h->mv_buf);
+    for (auto e : h->ev_b2) (void)hipEventDestroy(e);
     for (auto e : h->ev_col) (void)hipEventDestroy(e);
     for (auto e : h->ev_pan) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -1015,6 +1018,11 @@ static int ensure_events(ck_handle* h) {
         h->ev_col.push_back(a);
         h->ev_pan.push_back(b);
     }
+    while ((int)h->ev_b2.size() < h->nK + 1) {
+        hipEvent_t a;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        h->ev_b2.push_back(a);
+    }
     return 0;
 }
 
@@ -1436,6 +1444,9 @@ static int tall_sweeps(ck_handle* h) {
         ck_launch_tall_group(st, h->d_sigptr, h->aux, h->mpad, K0, np, J0, nJ, h->nend, h->tall_thin ? h->m + 1 : 0);
         gemm_timed_end(h, st);
     };
+    // option "tall_b2_stream": B2(g) on the handle's own stream instead of behind B1(g) on T -- the two only need group g's panels,
+    // so the partly filled last round of B1(g) runs beside B2(g)'s tiles instead of in front of them
+    const bool b2m = h->tall_b2_stream != 0;
     HIPCHK(hipEventRecord(h->ev0, M));
     HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
     HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
@@ -1456,10 +1467,17 @@ static int tall_sweeps(ck_handle* h) {
         }
         HIPCHK(hipStreamWaitEvent(T, h->ev_pan[g], 0));
         if (g + 2 < ng) {
+            // (B2 on its own stream: B2(g - 1) was the last writer of the block columns B1(g) updates)
+            if (b2m && g >= 1 && g + 2 < ng) HIPCHK(hipStreamWaitEvent(T, h->ev_b2[g - 1], 0));
             update(T, K0, Gc, first(g + 2), count(g + 2));                    // B1(g)
             HIPCHK(hipEventRecord(h->ev_col[g], T));
         }
-        if (g + 3 < ng) update(T, K0, Gc, first(g + 3), h->nK - first(g + 3));   // B2(g)
+        if (g + 3 < ng) {
+            hipStream_t B = b2m ? M : T;
+            if (b2m) HIPCHK(hipStreamWaitEvent(M, h->ev_pan[g], 0));
+            update(B, K0, Gc, first(g + 3), h->nK - first(g + 3));            // B2(g)
+        }
+        if (b2m) HIPCHK(hipEventRecord(h->ev_b2[g], M));
     }
     HIPCHK(hipEventRecord(h->ev1, C));               // end of the chain: the last panel is final
     HIPCHK(hipEventRecord(h->ev2, T));
@@ -2942,6 +2960,10 @@ extern "C" int ck_set_option(ck_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "solve_la")) {
         if (value < -1 || value > 1) return fail("solve_la must be -1, 0 or 1");
         h->solve_la = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "tall_b2_stream")) {
+        h->tall_b2_stream = value != 0;
         return 0;
     }
     if (!strcmp(name, "tall_thin")) {

@@ -655,11 +655,13 @@ def test_tall_sweep_many_panels_every_group_size(native, group, m):
     assert info == 0 and np.array_equal(p3, ref[0]) and np.array_equal(e3, ref[1])
     # the split panel step (option tall_split; automatic from 12 288 rows behind the first group): the cooperative launch on the
     # 512 x 512 head only, every other row -- Sigma's and the right-hand sides' -- through k_panel_rows_all in one launch
+    # (and B2(g) behind B1(g) on one stream instead of beside it on the handle's own: option tall_b2_stream)
     for split, rows in ((1, 0), (2, 1024), (0, 0)):
         h4, _ = _assembled(native, params, coords, values, HAV)
         h4.set_option("fused_group", group)
         h4.set_option("tall_split", split)
         h4.set_option("tall_split_rows", rows)
+        h4.set_option("tall_b2_stream", 0 if split == 1 else 1)
         info, p4, e4 = h4.factor_predict(1, pc)
         assert info == 0 and np.array_equal(p4, ref[0]) and np.array_equal(e4, ref[1]), (split, rows)
         assert h4.timings()["panel_coop_redone"] == 0
