@@ -366,7 +366,7 @@ int ck_table_fallbacks(ck_handle* h, int reset, int64_t* count);
  * waits for the head (same bits; N = 40 000: 0.5 % faster);
  * "solve_la" (-1 automatic = from 40 panels, 0, 1): ck_predict's sweep on a resident factor with the chain of the next panel group (the
  * one-column in-group updates, which fill 55 % of the chip, and the rows' walk through each panel) on the high-priority stream UNDER the
- * bulk update of the current group instead of in front of it (N = 40 000: 210 -> 205 ms; same bits);
+ * bulk update of the current group instead of in front of it (N = 40 000: 210 -> 200 ms; same bits);
  * "tall_b2_stream" (0/1, default 1): the tall sweep's update "group g -> everything beyond the next two groups" on the handle's own stream
  * beside the update of the group after next, instead of behind it on one stream (both only wait for group g's panels; 0.2 %);
  * "tall_thin" (0/1, default 1): a last right-hand-side tile row with at most 16 rows in front of the padding (m + 1 = 8 834: two rows)

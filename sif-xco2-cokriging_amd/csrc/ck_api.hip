@@ -1245,6 +1245,7 @@ static int solve_sweep_la(ck_handle* h) {
         ck_launch_aux_group(st, h->aux, h->mpad, h->d_panelptr, K0, np, J0, nJ, aux_rows(h, K0 + np - 1), h->nend, aux_live(h));
         gemm_timed_end(h, st);
     };
+    const bool b2m = h->tall_b2_stream != 0;
     HIPCHK(hipEventRecord(h->ev0, M));   // (ev0 / ev1 are free between ck_aux_begin and ck_aux_finish)
     HIPCHK(hipStreamWaitEvent(C, h->ev0, 0));
     HIPCHK(hipStreamWaitEvent(T, h->ev0, 0));
@@ -1261,10 +1262,15 @@ static int solve_sweep_la(ck_handle* h) {
         }
         HIPCHK(hipStreamWaitEvent(T, h->ev_pan[g], 0));
         if (g + 2 < ng) {
+            if (b2m && g >= 1) HIPCHK(hipStreamWaitEvent(T, h->ev_b2[g - 1], 0));   // B2(g - 1) wrote these block columns last
             update(T, K0, Gc, first(g + 2), count(g + 2));                    // B1(g)
             HIPCHK(hipEventRecord(h->ev_col[g], T));
         }
-        if (g + 3 < ng) update(T, K0, Gc, first(g + 3), h->nK - first(g + 3));   // B2(g)
+        if (g + 3 < ng) {
+            if (b2m) HIPCHK(hipStreamWaitEvent(M, h->ev_pan[g], 0));
+            update(b2m ? M : T, K0, Gc, first(g + 3), h->nK - first(g + 3));   // B2(g): beside B1(g) on the handle's own stream
+        }
+        if (b2m) HIPCHK(hipEventRecord(h->ev_b2[g], M));
     }
     HIPCHK(hipEventRecord(h->ev1, C));
     HIPCHK(hipEventRecord(h->ev_col[(size_t)h->nK], T));   // (ensure_events: nK + 1 entries, the groups use at most nK)
